@@ -1,0 +1,116 @@
+/*
+ * libmsda — multi-scale deformable attention (MSDeformAttn) for AMD Instinct MI355X (gfx950).
+ *
+ * C ABI of the hot path.  Plain pointers and sizes only; every buffer is allocated and owned by
+ * the caller and lives in device (HBM) memory of the GPU that is current when the call is made.
+ * The library never allocates, frees or retains pointers, never synchronises the device, and
+ * launches asynchronously on the HIP stream it is given (NULL = the default stream).  There is
+ * no global mutable state: the entry points may be called concurrently from several host
+ * threads (autograd runs the backward on its own engine thread).
+ *
+ * Tensor conventions (contiguous, row-major):
+ *   value   (N, S, M, D)         S = sum_l H_l * W_l
+ *   shapes  (L, 2) int64         (H_l, W_l), device memory
+ *   lsi     (L,)   int64         first index of level l inside S, device memory
+ *   loc     (N, Lq, M, L, P, 2)  (x, y) normalised to [0, 1]
+ *   attn    (N, Lq, M, L, P)
+ *   out     (N, Lq, M * D)
+ *
+ * Return value of every int-returning entry point: 0 on success, a negative MSDA_E* code for an
+ * argument error (nothing was launched), a positive hipError_t if a launch failed.
+ */
+#ifndef MSDA_H_
+#define MSDA_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* element types of value/out/grad tensors (dtype_val) and of loc/attn tensors (dtype_loc) */
+enum {
+  MSDA_F32 = 0,
+  MSDA_F64 = 1,
+  MSDA_BF16 = 2,
+  MSDA_F16 = 3,
+};
+
+/* argument errors */
+enum {
+  MSDA_OK = 0,
+  MSDA_ENULL = -1,      /* a required pointer is NULL */
+  MSDA_ESHAPE = -2,     /* a dimension is < 1 or a product overflows 2^31-1 where it must not */
+  MSDA_EDTYPE = -3,     /* unsupported dtype or dtype combination */
+  MSDA_EALIGN = -4,     /* a pointer is not aligned to its element type (16 B for fast paths) */
+  MSDA_EWORKSPACE = -5, /* workspace missing or smaller than msda_backward_workspace_bytes() */
+  MSDA_ESTEP = -6,      /* im2col_step < 1 or N % min(N, im2col_step) != 0 */
+  MSDA_ELEVELS = -7,    /* more levels or points than the library supports (L <= 16, L*P <= 128) */
+};
+
+/* flags for msda_backward */
+enum {
+  /* Compute grad_value without atomics, by a per-destination gather in a fixed order: bitwise
+   * reproducible, O(S * Lq * P) per head and channel — meant for small problems (gradcheck,
+   * debugging), not for throughput. */
+  MSDA_FLAG_DETERMINISTIC = 1,
+  /* Force the generic (any D, one lane per channel) kernels even where a tuned path exists. */
+  MSDA_FLAG_GENERIC = 2,
+};
+
+/* Library ABI version (bumped when a signature changes). */
+int msda_version(void);
+
+/* Human-readable text for a return code of this library (static storage). */
+const char* msda_error_string(int code);
+
+/*
+ * Batch-chunking knob of the reference signature
+ * (`MultiScaleDeformAttnFunction.apply(..., im2col_step)`,
+ * tests/unipercept/nn/layers/test_nn_layers_deform_attn.py:51-58 and :34,142 of the reference).
+ * The kernels here take the whole batch in one launch, so the value only has to be valid:
+ * step = min(N, im2col_step) must be >= 1 and divide N.  Returns 0 or MSDA_ESTEP.
+ */
+int msda_check_im2col_step(int N, int im2col_step);
+
+/*
+ * Forward: out[b,q,m*D:(m+1)*D] = sum_{l,p} attn[b,q,m,l,p] * bilinear(value_l[b,:,m,:], loc[b,q,m,l,p]).
+ * Replaces `MultiScaleDeformAttnFunction.forward`
+ * (tests/unipercept/nn/layers/test_nn_layers_deform_attn.py:51-58 of the reference; numerically the
+ * same as `reference.deform_attn`, same file :40-49).
+ *
+ * dtype_val in {F32, F64, BF16, F16}; dtype_loc == dtype_val, or F32 with a 16-bit dtype_val.
+ * Accumulation is fp32 (fp64 for F64).
+ */
+int msda_forward(const void* value, const int64_t* shapes_dev, const int64_t* lsi_dev,
+                 const void* loc, const void* attn, void* out, int N, int S, int M, int D, int Lq,
+                 int L, int P, int dtype_val, int dtype_loc, int flags, void* hip_stream);
+
+/*
+ * Scratch the backward needs, in bytes (0 when none).  Non-zero for 16-bit value dtypes
+ * (an fp32 accumulation image of grad_value) and for the binned grad_value path.
+ */
+size_t msda_backward_workspace_bytes(int N, int S, int M, int D, int Lq, int L, int P,
+                                     int dtype_val, int dtype_loc, int flags);
+
+/*
+ * Backward: grad_value (N,S,M,D), grad_loc (N,Lq,M,L,P,2), grad_attn (N,Lq,M,L,P) for a given
+ * grad_out (N,Lq,M*D).  Replaces `MultiScaleDeformAttnFunction.backward` (exercised by gradcheck
+ * at tests/unipercept/nn/layers/test_nn_layers_deform_attn.py:149-159 of the reference).
+ *
+ * All three outputs are fully overwritten; grad_value is zeroed by the callee (no need to
+ * pre-zero).  `workspace` must hold msda_backward_workspace_bytes(...) bytes, 256-B aligned
+ * (may be NULL when that is 0); its contents on entry are ignored and on return undefined.
+ * grad_loc / grad_attn have dtype_loc, grad_value has dtype_val.
+ */
+int msda_backward(const void* grad_out, const void* value, const int64_t* shapes_dev,
+                  const int64_t* lsi_dev, const void* loc, const void* attn, void* grad_value,
+                  void* grad_loc, void* grad_attn, void* workspace, size_t workspace_bytes, int N,
+                  int S, int M, int D, int Lq, int L, int P, int dtype_val, int dtype_loc,
+                  int flags, void* hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MSDA_H_ */

@@ -1,0 +1,81 @@
+"""ctypes binding of ``libmsda.so`` (the C ABI in ``include/msda.h``)."""
+
+from __future__ import annotations
+
+import ctypes
+import os
+import threading
+from pathlib import Path
+
+_PKG = Path(__file__).resolve().parent
+LIB_PATH = Path(os.environ.get("MSDA_LIBRARY", _PKG / "libmsda.so"))
+
+ABI_VERSION = 1
+
+# dtype codes of include/msda.h
+F32, F64, BF16, F16 = 0, 1, 2, 3
+FLAG_DETERMINISTIC = 1
+FLAG_GENERIC = 2
+
+# every symbol include/msda.h declares
+EXPORTS = (
+    "msda_version",
+    "msda_error_string",
+    "msda_check_im2col_step",
+    "msda_forward",
+    "msda_backward_workspace_bytes",
+    "msda_backward",
+)
+
+_lock = threading.Lock()
+_lib = None
+
+
+class MsdaLibraryError(RuntimeError):
+    pass
+
+
+def _declare(lib: ctypes.CDLL) -> None:
+    c_int, c_vp, c_sz = ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t
+    lib.msda_version.restype = c_int
+    lib.msda_version.argtypes = []
+    lib.msda_error_string.restype = ctypes.c_char_p
+    lib.msda_error_string.argtypes = [c_int]
+    lib.msda_check_im2col_step.restype = c_int
+    lib.msda_check_im2col_step.argtypes = [c_int, c_int]
+    lib.msda_forward.restype = c_int
+    lib.msda_forward.argtypes = [c_vp] * 6 + [c_int] * 7 + [c_int, c_int, c_int, c_vp]
+    lib.msda_backward_workspace_bytes.restype = c_sz
+    lib.msda_backward_workspace_bytes.argtypes = [c_int] * 7 + [c_int, c_int, c_int]
+    lib.msda_backward.restype = c_int
+    lib.msda_backward.argtypes = [c_vp] * 10 + [c_sz] + [c_int] * 7 + [c_int, c_int, c_int, c_vp]
+
+
+def load() -> ctypes.CDLL:
+    """Loads the HIP library; raises if it has not been built (no fallback exists)."""
+    global _lib
+    if _lib is None:
+        with _lock:
+            if _lib is None:
+                if not LIB_PATH.exists():
+                    raise MsdaLibraryError(
+                        f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; "
+                        "g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback."
+                    )
+                lib = ctypes.CDLL(str(LIB_PATH))
+                missing = [s for s in EXPORTS if not hasattr(lib, s)]
+                if missing:
+                    raise MsdaLibraryError(f"{LIB_PATH} lacks symbols {missing}")
+                _declare(lib)
+                if lib.msda_version() != ABI_VERSION:
+                    raise MsdaLibraryError(
+                        f"{LIB_PATH} has ABI version {lib.msda_version()}, expected {ABI_VERSION}"
+                    )
+                _lib = lib
+    return _lib
+
+
+def check(code: int, what: str) -> None:
+    if code != 0:
+        msg = load().msda_error_string(code).decode()
+        raise RuntimeError(f"{what} failed ({code}): {msg}")

@@ -1,0 +1,255 @@
+// libmsda: C ABI + launch logic of the MSDeformAttn kernels for gfx950 (see include/msda.h).
+#include "../../include/msda.h"
+
+#include <hip/hip_runtime.h>
+
+#include "msda_generic.h"
+#include "msda_tuned.h"
+
+namespace {
+
+using namespace msda;
+
+constexpr int kAbiVersion = 1;
+
+inline size_t elem_size(int dtype) {
+  switch (dtype) {
+    case MSDA_F32: return 4;
+    case MSDA_F64: return 8;
+    case MSDA_BF16:
+    case MSDA_F16: return 2;
+    default: return 0;
+  }
+}
+
+inline bool aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
+
+inline int check_common(int N, int S, int M, int D, int Lq, int L, int P, int dtype_val,
+                        int dtype_loc) {
+  if (N < 1 || S < 1 || M < 1 || D < 1 || Lq < 1 || L < 1 || P < 1) return MSDA_ESHAPE;
+  if (L > kMaxLevels || static_cast<int64_t>(L) * P > 128) return MSDA_ELEVELS;
+  const int64_t lim = INT32_MAX;
+  if (static_cast<int64_t>(N) * Lq * M > lim || static_cast<int64_t>(S) * M * D > lim ||
+      static_cast<int64_t>(M) * D > (1 << 24))
+    return MSDA_ESHAPE;
+  if (elem_size(dtype_val) == 0 || elem_size(dtype_loc) == 0) return MSDA_EDTYPE;
+  const bool same = dtype_val == dtype_loc;
+  const bool mixed = (dtype_val == MSDA_BF16 || dtype_val == MSDA_F16) && dtype_loc == MSDA_F32;
+  if (!same && !mixed) return MSDA_EDTYPE;
+  return MSDA_OK;
+}
+
+inline int group_lanes(int D) { return D <= 8 ? 8 : D <= 16 ? 16 : D <= 32 ? 32 : 64; }
+
+inline int launch_status() {
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? MSDA_OK : static_cast<int>(e);
+}
+
+struct Dims {
+  int N, S, M, D, Lq, L, P;
+};
+
+// ---- generic forward ------------------------------------------------------------------------
+template <typename VT, typename LT>
+int fwd_generic(const void* value, const int64_t* shapes, const int64_t* lsi, const void* loc,
+                const void* attn, void* out, const Dims& d, hipStream_t stream) {
+  const int64_t groups = static_cast<int64_t>(d.N) * d.Lq * d.M;
+  const int G = group_lanes(d.D);
+  const int64_t blocks = (groups + (256 / G) - 1) / (256 / G);
+  if (blocks > INT32_MAX) return MSDA_ESHAPE;
+#define MSDA_LAUNCH(GG)                                                                          \
+  hipLaunchKernelGGL((fwd_generic_kernel<VT, LT, GG>), dim3(static_cast<unsigned>(blocks)),      \
+                     dim3(256), 0, stream, static_cast<const VT*>(value), shapes, lsi,           \
+                     static_cast<const LT*>(loc), static_cast<const LT*>(attn),                  \
+                     static_cast<VT*>(out), groups, d.S, d.M, d.D, d.Lq, d.L, d.P)
+  switch (G) {
+    case 8: MSDA_LAUNCH(8); break;
+    case 16: MSDA_LAUNCH(16); break;
+    case 32: MSDA_LAUNCH(32); break;
+    default: MSDA_LAUNCH(64); break;
+  }
+#undef MSDA_LAUNCH
+  return launch_status();
+}
+
+// ---- generic backward -----------------------------------------------------------------------
+template <typename VT, typename LT, typename GT>
+int bwd_generic(const void* grad_out, const void* value, const int64_t* shapes, const int64_t* lsi,
+                const void* loc, const void* attn, void* grad_value, void* grad_loc,
+                void* grad_attn, void* workspace, const Dims& d, bool deterministic,
+                hipStream_t stream) {
+  const int64_t groups = static_cast<int64_t>(d.N) * d.Lq * d.M;
+  const int64_t total = static_cast<int64_t>(d.N) * d.S * d.M * d.D;
+  const int G = group_lanes(d.D);
+  const int64_t blocks = (groups + (256 / G) - 1) / (256 / G);
+  if (blocks > INT32_MAX) return MSDA_ESHAPE;
+  constexpr bool kDirect = sizeof(GT) == sizeof(VT);  // atomics go straight into grad_value
+  GT* acc = kDirect ? static_cast<GT*>(grad_value) : static_cast<GT*>(workspace);
+  if (!deterministic) {
+    const hipError_t e = hipMemsetAsync(acc, 0, static_cast<size_t>(total) * sizeof(GT), stream);
+    if (e != hipSuccess) return static_cast<int>(e);
+  }
+#define MSDA_LAUNCH(GG, SC)                                                                      \
+  hipLaunchKernelGGL((bwd_generic_kernel<VT, LT, GT, GG, SC>),                                   \
+                     dim3(static_cast<unsigned>(blocks)), dim3(256), 0, stream,                  \
+                     static_cast<const VT*>(grad_out), static_cast<const VT*>(value), shapes,    \
+                     lsi, static_cast<const LT*>(loc), static_cast<const LT*>(attn), acc,        \
+                     static_cast<LT*>(grad_loc), static_cast<LT*>(grad_attn), groups, d.S, d.M,  \
+                     d.D, d.Lq, d.L, d.P)
+#define MSDA_LAUNCH_G(SC)                 \
+  switch (G) {                            \
+    case 8: MSDA_LAUNCH(8, SC); break;    \
+    case 16: MSDA_LAUNCH(16, SC); break;  \
+    case 32: MSDA_LAUNCH(32, SC); break;  \
+    default: MSDA_LAUNCH(64, SC); break;  \
+  }
+  if (deterministic) {
+    MSDA_LAUNCH_G(false)
+  } else {
+    MSDA_LAUNCH_G(true)
+  }
+#undef MSDA_LAUNCH_G
+#undef MSDA_LAUNCH
+  int rc = launch_status();
+  if (rc != MSDA_OK) return rc;
+  if (deterministic) {
+    const int64_t vb = (total + 255) / 256;
+    if (vb > INT32_MAX) return MSDA_ESHAPE;
+    hipLaunchKernelGGL((bwd_value_gather_kernel<VT, LT>), dim3(static_cast<unsigned>(vb)),
+                       dim3(256), 0, stream, static_cast<const VT*>(grad_out), shapes, lsi,
+                       static_cast<const LT*>(loc), static_cast<const LT*>(attn),
+                       static_cast<VT*>(grad_value), total, d.S, d.M, d.D, d.Lq, d.L, d.P);
+    return launch_status();
+  }
+  if constexpr (!kDirect) {
+    const int64_t cb = (total + 255) / 256;
+    const unsigned grid = static_cast<unsigned>(cb < 8192 ? cb : 8192);
+    hipLaunchKernelGGL((convert_from_f32_kernel<VT>), dim3(grid), dim3(256), 0, stream,
+                       static_cast<const float*>(workspace), static_cast<VT*>(grad_value), total);
+    rc = launch_status();
+  }
+  return rc;
+}
+
+inline bool needs_f32_image(int dtype_val) { return dtype_val == MSDA_BF16 || dtype_val == MSDA_F16; }
+
+}  // namespace
+
+extern "C" {
+
+int msda_version(void) { return kAbiVersion; }
+
+const char* msda_error_string(int code) {
+  switch (code) {
+    case MSDA_OK: return "success";
+    case MSDA_ENULL: return "msda: a required pointer is NULL";
+    case MSDA_ESHAPE: return "msda: invalid dimension (must be >= 1 and within 32-bit index limits)";
+    case MSDA_EDTYPE: return "msda: unsupported dtype or dtype combination";
+    case MSDA_EALIGN: return "msda: pointer not aligned to its element type";
+    case MSDA_EWORKSPACE: return "msda: workspace missing, misaligned or too small";
+    case MSDA_ESTEP: return "msda: im2col_step must be >= 1 and min(N, im2col_step) must divide N";
+    case MSDA_ELEVELS: return "msda: too many levels/points (L <= 16, L*P <= 128)";
+    default:
+      return code > 0 ? hipGetErrorString(static_cast<hipError_t>(code)) : "msda: unknown error";
+  }
+}
+
+int msda_check_im2col_step(int N, int im2col_step) {
+  if (N < 1 || im2col_step < 1) return MSDA_ESTEP;
+  const int step = N < im2col_step ? N : im2col_step;
+  return (N % step == 0) ? MSDA_OK : MSDA_ESTEP;
+}
+
+int msda_forward(const void* value, const int64_t* shapes_dev, const int64_t* lsi_dev,
+                 const void* loc, const void* attn, void* out, int N, int S, int M, int D, int Lq,
+                 int L, int P, int dtype_val, int dtype_loc, int flags, void* hip_stream) {
+  if (!value || !shapes_dev || !lsi_dev || !loc || !attn || !out) return MSDA_ENULL;
+  const int rc = check_common(N, S, M, D, Lq, L, P, dtype_val, dtype_loc);
+  if (rc != MSDA_OK) return rc;
+  if (!aligned(value, elem_size(dtype_val)) || !aligned(out, elem_size(dtype_val)) ||
+      !aligned(loc, elem_size(dtype_loc)) || !aligned(attn, elem_size(dtype_loc)) ||
+      !aligned(shapes_dev, 8) || !aligned(lsi_dev, 8))
+    return MSDA_EALIGN;
+  const Dims d{N, S, M, D, Lq, L, P};
+  hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+
+  if (!(flags & MSDA_FLAG_GENERIC)) {
+    const int t = tuned_forward(value, shapes_dev, lsi_dev, loc, attn, out, N, S, M, D, Lq, L, P,
+                                dtype_val, dtype_loc, stream);
+    if (t != kNotTuned) return t;
+  }
+  switch (dtype_val) {
+    case MSDA_F32:
+      return fwd_generic<float, float>(value, shapes_dev, lsi_dev, loc, attn, out, d, stream);
+    case MSDA_F64:
+      return fwd_generic<double, double>(value, shapes_dev, lsi_dev, loc, attn, out, d, stream);
+    case MSDA_BF16:
+      return dtype_loc == MSDA_F32
+                 ? fwd_generic<bf16_t, float>(value, shapes_dev, lsi_dev, loc, attn, out, d, stream)
+                 : fwd_generic<bf16_t, bf16_t>(value, shapes_dev, lsi_dev, loc, attn, out, d, stream);
+    case MSDA_F16:
+      return dtype_loc == MSDA_F32
+                 ? fwd_generic<f16_t, float>(value, shapes_dev, lsi_dev, loc, attn, out, d, stream)
+                 : fwd_generic<f16_t, f16_t>(value, shapes_dev, lsi_dev, loc, attn, out, d, stream);
+  }
+  return MSDA_EDTYPE;
+}
+
+size_t msda_backward_workspace_bytes(int N, int S, int M, int D, int Lq, int L, int P,
+                                     int dtype_val, int dtype_loc, int flags) {
+  if (check_common(N, S, M, D, Lq, L, P, dtype_val, dtype_loc) != MSDA_OK) return 0;
+  if (flags & MSDA_FLAG_DETERMINISTIC) return 0;
+  if (!(flags & MSDA_FLAG_GENERIC)) {
+    const int64_t t = tuned_backward_workspace_bytes(N, S, M, D, Lq, L, P, dtype_val, dtype_loc);
+    if (t >= 0) return static_cast<size_t>(t);
+  }
+  if (needs_f32_image(dtype_val)) return static_cast<size_t>(N) * S * M * D * sizeof(float);
+  return 0;
+}
+
+int msda_backward(const void* grad_out, const void* value, const int64_t* shapes_dev,
+                  const int64_t* lsi_dev, const void* loc, const void* attn, void* grad_value,
+                  void* grad_loc, void* grad_attn, void* workspace, size_t workspace_bytes, int N,
+                  int S, int M, int D, int Lq, int L, int P, int dtype_val, int dtype_loc,
+                  int flags, void* hip_stream) {
+  if (!grad_out || !value || !shapes_dev || !lsi_dev || !loc || !attn || !grad_value ||
+      !grad_loc || !grad_attn)
+    return MSDA_ENULL;
+  const int rc = check_common(N, S, M, D, Lq, L, P, dtype_val, dtype_loc);
+  if (rc != MSDA_OK) return rc;
+  const size_t ev = elem_size(dtype_val), el = elem_size(dtype_loc);
+  if (!aligned(grad_out, ev) || !aligned(value, ev) || !aligned(grad_value, ev) ||
+      !aligned(loc, el) || !aligned(attn, el) || !aligned(grad_loc, el) ||
+      !aligned(grad_attn, el) || !aligned(shapes_dev, 8) || !aligned(lsi_dev, 8))
+    return MSDA_EALIGN;
+  const size_t need =
+      msda_backward_workspace_bytes(N, S, M, D, Lq, L, P, dtype_val, dtype_loc, flags);
+  if (need > 0 && (!workspace || workspace_bytes < need || !aligned(workspace, 256)))
+    return MSDA_EWORKSPACE;
+  const Dims d{N, S, M, D, Lq, L, P};
+  hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+  const bool det = (flags & MSDA_FLAG_DETERMINISTIC) != 0;
+
+  if (!det && !(flags & MSDA_FLAG_GENERIC)) {
+    const int t = tuned_backward(grad_out, value, shapes_dev, lsi_dev, loc, attn, grad_value,
+                                 grad_loc, grad_attn, workspace, N, S, M, D, Lq, L, P, dtype_val,
+                                 dtype_loc, stream);
+    if (t != kNotTuned) return t;
+  }
+#define MSDA_BWD(VT, LT, GT)                                                                  \
+  bwd_generic<VT, LT, GT>(grad_out, value, shapes_dev, lsi_dev, loc, attn, grad_value,        \
+                          grad_loc, grad_attn, workspace, d, det, stream)
+  switch (dtype_val) {
+    case MSDA_F32: return MSDA_BWD(float, float, float);
+    case MSDA_F64: return MSDA_BWD(double, double, double);
+    case MSDA_BF16:
+      return dtype_loc == MSDA_F32 ? MSDA_BWD(bf16_t, float, float) : MSDA_BWD(bf16_t, bf16_t, float);
+    case MSDA_F16:
+      return dtype_loc == MSDA_F32 ? MSDA_BWD(f16_t, float, float) : MSDA_BWD(f16_t, f16_t, float);
+  }
+#undef MSDA_BWD
+  return MSDA_EDTYPE;
+}
+
+}  // extern "C"

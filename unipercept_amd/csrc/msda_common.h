@@ -1,0 +1,107 @@
+// Shared device helpers for the MSDeformAttn kernels (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace msda {
+
+// ---- element types -------------------------------------------------------------------------
+struct bf16_t {
+  uint16_t bits;
+};
+using f16_t = _Float16;
+
+template <typename T>
+struct Elem;
+
+template <>
+struct Elem<float> {
+  using compute_t = float;
+  __device__ __forceinline__ static float load(const float* p) { return *p; }
+  __device__ __forceinline__ static void store(float* p, float v) { *p = v; }
+};
+template <>
+struct Elem<double> {
+  using compute_t = double;
+  __device__ __forceinline__ static double load(const double* p) { return *p; }
+  __device__ __forceinline__ static void store(double* p, double v) { *p = v; }
+};
+template <>
+struct Elem<bf16_t> {
+  using compute_t = float;
+  __device__ __forceinline__ static float load(const bf16_t* p) {
+    return __uint_as_float(static_cast<uint32_t>(p->bits) << 16);
+  }
+  __device__ __forceinline__ static void store(bf16_t* p, float v) {
+    // plain cast: v_cvt_pk_bf16_f32 on gfx950 (round-to-nearest-even, NaN stays NaN)
+    __bf16 h = static_cast<__bf16>(v);
+    p->bits = __builtin_bit_cast(uint16_t, h);
+  }
+};
+template <>
+struct Elem<f16_t> {
+  using compute_t = float;
+  __device__ __forceinline__ static float load(const f16_t* p) { return static_cast<float>(*p); }
+  __device__ __forceinline__ static void store(f16_t* p, float v) { *p = static_cast<f16_t>(v); }
+};
+
+__device__ __forceinline__ float bf16_bits_to_f32(uint32_t bits16) {
+  return __uint_as_float(bits16 << 16);
+}
+__device__ __forceinline__ uint32_t f32_to_bf16_bits(float v) {
+  __bf16 h = static_cast<__bf16>(v);
+  return static_cast<uint32_t>(__builtin_bit_cast(uint16_t, h));
+}
+
+// ---- one sampling point ----------------------------------------------------------------------
+// Bilinear footprint of one (x, y) location on an H x W level, following grid_sample(bilinear,
+// zeros, align_corners=False): pixel centres at integer + 0.5.  Corner k in {0,1,2,3} is
+// (y0, x0), (y0, x0+1), (y0+1, x0), (y0+1, x0+1).
+template <typename CT>
+struct Footprint {
+  CT w[4];      // bilinear weights (0 for a corner outside the level)
+  CT dwx[4];    // d w / d x   (0 for a corner outside the level)
+  CT dwy[4];    // d w / d y
+  int pix[4];   // y*W + x of the corner, clamped into the level (valid address even when w == 0)
+  bool valid[4];  // corner lies inside the level (and the point inside the skirt)
+  bool any;     // false when the point lies outside the (-1, H) x (-1, W) skirt: contributes nothing
+};
+
+template <typename CT>
+__device__ __forceinline__ Footprint<CT> footprint(CT locx, CT locy, int H, int W) {
+  Footprint<CT> f;
+  const CT x = locx * static_cast<CT>(W) - static_cast<CT>(0.5);
+  const CT y = locy * static_cast<CT>(H) - static_cast<CT>(0.5);
+  f.any = (y > static_cast<CT>(-1)) && (x > static_cast<CT>(-1)) && (y < static_cast<CT>(H)) &&
+          (x < static_cast<CT>(W)) && H > 0 && W > 0;
+  // clamp first so that the float->int conversion below is always defined (NaN/inf/huge inputs)
+  const CT xs = f.any ? x : static_cast<CT>(0);
+  const CT ys = f.any ? y : static_cast<CT>(0);
+  const CT xf = floor(xs), yf = floor(ys);
+  const int x0 = static_cast<int>(xf), y0 = static_cast<int>(yf);
+  const CT lx = xs - xf, ly = ys - yf, hx = static_cast<CT>(1) - lx, hy = static_cast<CT>(1) - ly;
+  const bool vx0 = f.any && x0 >= 0, vx1 = f.any && x0 + 1 < W;
+  const bool vy0 = f.any && y0 >= 0, vy1 = f.any && y0 + 1 < H;
+  const int xc0 = max(x0, 0), xc1 = max(min(x0 + 1, W - 1), 0);
+  const int yc0 = max(y0, 0), yc1 = max(min(y0 + 1, H - 1), 0);
+  const CT z = static_cast<CT>(0);
+  const bool v[4] = {vy0 && vx0, vy0 && vx1, vy1 && vx0, vy1 && vx1};
+  const CT w[4] = {hy * hx, hy * lx, ly * hx, ly * lx};
+  const CT dx[4] = {-hy, hy, -ly, ly};
+  const CT dy[4] = {-hx, -lx, hx, lx};
+  f.pix[0] = yc0 * W + xc0;
+  f.pix[1] = yc0 * W + xc1;
+  f.pix[2] = yc1 * W + xc0;
+  f.pix[3] = yc1 * W + xc1;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    f.valid[k] = v[k];
+    f.w[k] = v[k] ? w[k] : z;
+    f.dwx[k] = v[k] ? dx[k] : z;
+    f.dwy[k] = v[k] ? dy[k] : z;
+  }
+  return f;
+}
+
+}  // namespace msda

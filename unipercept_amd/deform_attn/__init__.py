@@ -1,0 +1,12 @@
+"""Drop-in for ``unipercept.nn.layers.deform_attn`` on MI355X.
+
+Exports what the reference's test imports from that package
+(tests/unipercept/nn/layers/test_nn_layers_deform_attn.py:6-10): ``MultiScaleDeformAttnFunction``
+and ``reference``; plus the functional alias ``ms_deform_attn`` and the ``MSDeformAttn`` layer.
+"""
+
+from . import reference
+from ._function import MultiScaleDeformAttnFunction, ms_deform_attn
+from .layer import MSDeformAttn
+
+__all__ = ["MSDeformAttn", "MultiScaleDeformAttnFunction", "ms_deform_attn", "reference"]

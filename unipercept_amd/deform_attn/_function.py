@@ -1,0 +1,90 @@
+"""Autograd entry points with the reference's signatures.
+
+``MultiScaleDeformAttnFunction.apply(value, spatial_shapes, level_start_index,
+sampling_locations, attention_weights, im2col_step)`` is the call the reference's test makes
+(tests/unipercept/nn/layers/test_nn_layers_deform_attn.py:51-58,143-159).
+"""
+
+from __future__ import annotations
+
+import os
+
+import torch
+from torch.autograd.function import once_differentiable
+
+from .. import _lib
+from . import _ops
+
+# fp64 exists for gradcheck; below this much work the reproducible (atomic-free) grad_value path
+# is used for it, so that two backward passes agree bitwise (gradcheck's default nondet_tol is 0)
+_DET_FP64_WORK_LIMIT = 1 << 31
+
+
+def backward_flags(value: torch.Tensor, sampling_locations: torch.Tensor) -> int:
+    flags = 0
+    if os.environ.get("MSDA_FORCE_GENERIC") == "1":
+        flags |= _lib.FLAG_GENERIC
+    det = os.environ.get("MSDA_DETERMINISTIC")
+    if det == "1" or (det != "0" and torch.are_deterministic_algorithms_enabled()):
+        flags |= _lib.FLAG_DETERMINISTIC
+    elif det != "0" and value.dtype == torch.float64:
+        lq, p = sampling_locations.shape[1], sampling_locations.shape[4]
+        if value.numel() * lq * p <= _DET_FP64_WORK_LIMIT:
+            flags |= _lib.FLAG_DETERMINISTIC
+    return flags
+
+
+def forward_flags() -> int:
+    return _lib.FLAG_GENERIC if os.environ.get("MSDA_FORCE_GENERIC") == "1" else 0
+
+
+class MultiScaleDeformAttnFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(
+        ctx,
+        value: torch.Tensor,
+        spatial_shapes: torch.Tensor,
+        level_start_index: torch.Tensor,
+        sampling_locations: torch.Tensor,
+        attention_weights: torch.Tensor,
+        im2col_step: int = 64,
+    ) -> torch.Tensor:
+        _lib.check(
+            _lib.load().msda_check_im2col_step(int(value.shape[0]), int(im2col_step)),
+            "im2col_step check",
+        )
+        ctx.im2col_step = int(im2col_step)
+        out = _ops.ms_deform_attn_fwd(
+            value, spatial_shapes, level_start_index, sampling_locations, attention_weights,
+            forward_flags(),
+        )
+        ctx.save_for_backward(
+            value, spatial_shapes, level_start_index, sampling_locations, attention_weights
+        )
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_output: torch.Tensor):
+        value, spatial_shapes, level_start_index, sampling_locations, attention_weights = (
+            ctx.saved_tensors
+        )
+        grad_value, grad_loc, grad_attn = _ops.ms_deform_attn_bwd(
+            grad_output, value, spatial_shapes, level_start_index, sampling_locations,
+            attention_weights, backward_flags(value, sampling_locations),
+        )
+        return grad_value, None, None, grad_loc, grad_attn, None
+
+
+def ms_deform_attn(
+    value: torch.Tensor,
+    spatial_shapes: torch.Tensor,
+    level_start_index: torch.Tensor,
+    sampling_locations: torch.Tensor,
+    attention_weights: torch.Tensor,
+    im2col_step: int = 64,
+) -> torch.Tensor:
+    """Functional form: (N,S,M,D), (L,2), (L,), (N,Lq,M,L,P,2), (N,Lq,M,L,P) -> (N,Lq,M*D)."""
+    return MultiScaleDeformAttnFunction.apply(
+        value, spatial_shapes, level_start_index, sampling_locations, attention_weights, im2col_step
+    )

@@ -1,0 +1,187 @@
+"""PyTorch-ROCm custom-op layer over the C ABI (``include/msda.h``).
+
+Registers ``unipercept::ms_deform_attn_fwd`` / ``unipercept::ms_deform_attn_bwd`` with
+``torch.library`` (the reference's custom-op idiom: sources/unipercept/vision/inpaint.py:94-140),
+so autograd, DDP and ``torch.compile`` see two opaque ops.  Both run only on a ROCm device
+through ``libmsda.so``; there is no CPU implementation.
+"""
+
+from __future__ import annotations
+
+import os
+
+import torch
+
+from .. import _lib
+
+_DTYPE_CODE = {
+    torch.float32: _lib.F32,
+    torch.float64: _lib.F64,
+    torch.bfloat16: _lib.BF16,
+    torch.float16: _lib.F16,
+}
+
+_level_cache: dict[tuple, tuple] = {}
+
+
+def _dims(value, loc):
+    n, s, m, d = value.shape
+    _, lq, _, l, p, _ = loc.shape
+    return n, s, m, d, lq, l, p
+
+
+def _check_levels(shapes: torch.Tensor, lsi: torch.Tensor, s: int) -> None:
+    """Host-side consistency check of the level table (cached: it costs one device sync)."""
+    if os.environ.get("MSDA_SKIP_LEVEL_CHECK") == "1":
+        return
+    key = (shapes.data_ptr(), shapes._version, lsi.data_ptr(), lsi._version, s, shapes.device)
+    if key in _level_cache:
+        return
+    if torch.cuda.is_current_stream_capturing():
+        return  # cannot synchronise while a graph is being captured; the kernels guard themselves
+    hw = shapes.tolist()
+    st = lsi.tolist()
+    run = 0
+    for (h, w), start in zip(hw, st):
+        if h < 1 or w < 1:
+            raise ValueError(f"spatial_shapes must be positive, got {hw}")
+        if start != run:
+            raise ValueError(
+                f"level_start_index {st} is not the exclusive prefix sum of H*W of spatial_shapes {hw}"
+            )
+        run += h * w
+    if run != s:
+        raise ValueError(f"value has {s} positions but spatial_shapes {hw} cover {run}")
+    if len(_level_cache) > 256:
+        _level_cache.clear()
+    _level_cache[key] = (hw, st)
+
+
+def _validate(value, shapes, lsi, loc, attn):
+    if value.device.type != "cuda":
+        raise RuntimeError(
+            "ms_deform_attn runs only on a ROCm GPU (HIP kernels); got a tensor on "
+            f"{value.device}. Use `reference.deform_attn` for a pure-PyTorch CPU evaluation."
+        )
+    if value.dim() != 4 or loc.dim() != 6 or attn.dim() != 5 or loc.shape[-1] != 2:
+        raise ValueError(
+            "expected value (N,S,M,D), sampling_locations (N,Lq,M,L,P,2), attention_weights "
+            f"(N,Lq,M,L,P); got {tuple(value.shape)}, {tuple(loc.shape)}, {tuple(attn.shape)}"
+        )
+    n, s, m, d, lq, l, p = _dims(value, loc)
+    if loc.shape[0] != n or loc.shape[2] != m or tuple(attn.shape) != (n, lq, m, l, p):
+        raise ValueError(
+            f"inconsistent shapes: value {tuple(value.shape)}, sampling_locations "
+            f"{tuple(loc.shape)}, attention_weights {tuple(attn.shape)}"
+        )
+    if tuple(shapes.shape) != (l, 2) or tuple(lsi.shape) != (l,):
+        raise ValueError(
+            f"spatial_shapes must be ({l}, 2) and level_start_index ({l},); got "
+            f"{tuple(shapes.shape)} and {tuple(lsi.shape)}"
+        )
+    if value.dtype not in _DTYPE_CODE:
+        raise TypeError(f"unsupported value dtype {value.dtype}")
+    for t in (loc, attn):
+        if t.device != value.device:
+            raise RuntimeError("all tensors must live on the same device")
+
+
+def _prepare(value, shapes, lsi, loc, attn):
+    """Returns contiguous, dtype-consistent tensors on value's device."""
+    _validate(value, shapes, lsi, loc, attn)
+    dev = value.device
+    shapes = shapes.to(device=dev, dtype=torch.int64).contiguous()
+    lsi = lsi.to(device=dev, dtype=torch.int64).contiguous()
+    vdt = value.dtype
+    # supported: loc/attn in value's dtype, or fp32 next to a 16-bit value
+    if loc.dtype == torch.float32 and vdt in (torch.bfloat16, torch.float16):
+        ldt = torch.float32
+    else:
+        ldt = vdt
+    loc = loc.to(ldt).contiguous()
+    attn = attn.to(ldt).contiguous()
+    value = value.contiguous()
+    _check_levels(shapes, lsi, value.shape[1])
+    return value, shapes, lsi, loc, attn
+
+
+def _stream_ptr(device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+@torch.library.custom_op("unipercept::ms_deform_attn_fwd", mutates_args=())
+def ms_deform_attn_fwd(
+    value: torch.Tensor,
+    spatial_shapes: torch.Tensor,
+    level_start_index: torch.Tensor,
+    sampling_locations: torch.Tensor,
+    attention_weights: torch.Tensor,
+    flags: int,
+) -> torch.Tensor:
+    lib = _lib.load()
+    value, shapes, lsi, loc, attn = _prepare(
+        value, spatial_shapes, level_start_index, sampling_locations, attention_weights
+    )
+    n, s, m, d, lq, l, p = _dims(value, loc)
+    out = torch.empty((n, lq, m * d), dtype=value.dtype, device=value.device)
+    with torch.cuda.device_of(value):
+        rc = lib.msda_forward(
+            value.data_ptr(), shapes.data_ptr(), lsi.data_ptr(), loc.data_ptr(), attn.data_ptr(),
+            out.data_ptr(), n, s, m, d, lq, l, p, _DTYPE_CODE[value.dtype], _DTYPE_CODE[loc.dtype],
+            flags, _stream_ptr(value.device),
+        )
+    _lib.check(rc, "msda_forward")
+    return out
+
+
+@ms_deform_attn_fwd.register_fake
+def _(value, spatial_shapes, level_start_index, sampling_locations, attention_weights, flags):
+    n, _, m, d = value.shape
+    return value.new_empty((n, sampling_locations.shape[1], m * d))
+
+
+@torch.library.custom_op("unipercept::ms_deform_attn_bwd", mutates_args=())
+def ms_deform_attn_bwd(
+    grad_output: torch.Tensor,
+    value: torch.Tensor,
+    spatial_shapes: torch.Tensor,
+    level_start_index: torch.Tensor,
+    sampling_locations: torch.Tensor,
+    attention_weights: torch.Tensor,
+    flags: int,
+) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    lib = _lib.load()
+    loc_dtype, attn_dtype = sampling_locations.dtype, attention_weights.dtype
+    value, shapes, lsi, loc, attn = _prepare(
+        value, spatial_shapes, level_start_index, sampling_locations, attention_weights
+    )
+    n, s, m, d, lq, l, p = _dims(value, loc)
+    grad_output = grad_output.to(value.dtype).contiguous()
+    if tuple(grad_output.shape) != (n, lq, m * d):
+        raise ValueError(f"grad_output must be {(n, lq, m * d)}, got {tuple(grad_output.shape)}")
+    grad_value = torch.empty_like(value)
+    grad_loc = torch.empty_like(loc)
+    grad_attn = torch.empty_like(attn)
+    vcode, lcode = _DTYPE_CODE[value.dtype], _DTYPE_CODE[loc.dtype]
+    with torch.cuda.device_of(value):
+        nbytes = lib.msda_backward_workspace_bytes(n, s, m, d, lq, l, p, vcode, lcode, flags)
+        workspace = (
+            torch.empty(nbytes, dtype=torch.uint8, device=value.device) if nbytes else None
+        )
+        rc = lib.msda_backward(
+            grad_output.data_ptr(), value.data_ptr(), shapes.data_ptr(), lsi.data_ptr(),
+            loc.data_ptr(), attn.data_ptr(), grad_value.data_ptr(), grad_loc.data_ptr(),
+            grad_attn.data_ptr(), workspace.data_ptr() if nbytes else None, nbytes,
+            n, s, m, d, lq, l, p, vcode, lcode, flags, _stream_ptr(value.device),
+        )
+    _lib.check(rc, "msda_backward")
+    return grad_value, grad_loc.to(loc_dtype), grad_attn.to(attn_dtype)
+
+
+@ms_deform_attn_bwd.register_fake
+def _(grad_output, value, spatial_shapes, level_start_index, sampling_locations, attention_weights, flags):
+    return (
+        torch.empty_like(value),
+        torch.empty_like(sampling_locations),
+        torch.empty_like(attention_weights),
+    )

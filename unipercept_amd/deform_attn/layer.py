@@ -1,0 +1,114 @@
+"""``MSDeformAttn`` layer: linear projections on PyTorch-ROCm GEMMs around the HIP op.
+
+The reference snapshot holds no such module (its ``nn/layers/deform_attn`` package is absent);
+the interface follows the Deformable-DETR / Mask2Former pixel-decoder convention that the
+reference's models call: ``forward(query, reference_points, input_flatten,
+input_spatial_shapes, input_level_start_index, input_padding_mask=None)``.
+"""
+
+from __future__ import annotations
+
+import math
+
+import torch
+from torch import nn
+
+from ._function import MultiScaleDeformAttnFunction
+
+
+class MSDeformAttn(nn.Module):
+    def __init__(
+        self,
+        d_model: int = 256,
+        n_levels: int = 4,
+        n_heads: int = 8,
+        n_points: int = 4,
+        im2col_step: int = 64,
+    ):
+        super().__init__()
+        if d_model % n_heads != 0:
+            raise ValueError(f"d_model ({d_model}) must be divisible by n_heads ({n_heads})")
+        self.d_model = d_model
+        self.n_levels = n_levels
+        self.n_heads = n_heads
+        self.n_points = n_points
+        self.im2col_step = im2col_step
+
+        self.sampling_offsets = nn.Linear(d_model, n_heads * n_levels * n_points * 2)
+        self.attention_weights = nn.Linear(d_model, n_heads * n_levels * n_points)
+        self.value_proj = nn.Linear(d_model, d_model)
+        self.output_proj = nn.Linear(d_model, d_model)
+        self.reset_parameters()
+
+    def reset_parameters(self) -> None:
+        # offsets start as a ring of directions per head, growing with the point index
+        nn.init.zeros_(self.sampling_offsets.weight)
+        angle = torch.arange(self.n_heads, dtype=torch.float32) * (2.0 * math.pi / self.n_heads)
+        ring = torch.stack((angle.cos(), angle.sin()), dim=-1)
+        ring = ring / ring.abs().amax(dim=-1, keepdim=True)
+        ring = ring.view(self.n_heads, 1, 1, 2).repeat(1, self.n_levels, self.n_points, 1)
+        ring = ring * torch.arange(1, self.n_points + 1, dtype=torch.float32).view(1, 1, -1, 1)
+        with torch.no_grad():
+            self.sampling_offsets.bias.copy_(ring.reshape(-1))
+        nn.init.zeros_(self.attention_weights.weight)
+        nn.init.zeros_(self.attention_weights.bias)
+        nn.init.xavier_uniform_(self.value_proj.weight)
+        nn.init.zeros_(self.value_proj.bias)
+        nn.init.xavier_uniform_(self.output_proj.weight)
+        nn.init.zeros_(self.output_proj.bias)
+
+    def sampling_inputs(
+        self,
+        query: torch.Tensor,
+        reference_points: torch.Tensor,
+        input_flatten: torch.Tensor,
+        input_spatial_shapes: torch.Tensor,
+        input_padding_mask: torch.Tensor | None = None,
+    ):
+        """Projections and reference-point arithmetic: returns (value, locations, weights)."""
+        n, lq, _ = query.shape
+        _, s, _ = input_flatten.shape
+        value = self.value_proj(input_flatten)
+        if input_padding_mask is not None:
+            value = value.masked_fill(input_padding_mask[..., None], 0.0)
+        value = value.view(n, s, self.n_heads, self.d_model // self.n_heads)
+        offsets = self.sampling_offsets(query).view(
+            n, lq, self.n_heads, self.n_levels, self.n_points, 2
+        )
+        weights = self.attention_weights(query).view(n, lq, self.n_heads, self.n_levels * self.n_points)
+        weights = weights.softmax(-1).view(n, lq, self.n_heads, self.n_levels, self.n_points)
+        if reference_points.shape[-1] == 2:
+            # (W, H) per level: offsets are in pixels of the level they sample
+            wh = torch.stack((input_spatial_shapes[..., 1], input_spatial_shapes[..., 0]), -1)
+            locations = (
+                reference_points[:, :, None, :, None, :]
+                + offsets / wh.to(offsets.dtype)[None, None, None, :, None, :]
+            )
+        elif reference_points.shape[-1] == 4:
+            locations = (
+                reference_points[:, :, None, :, None, :2]
+                + offsets / self.n_points * reference_points[:, :, None, :, None, 2:] * 0.5
+            )
+        else:
+            raise ValueError(
+                f"last dim of reference_points must be 2 or 4, got {reference_points.shape[-1]}"
+            )
+        return value, locations, weights
+
+    def forward(
+        self,
+        query: torch.Tensor,
+        reference_points: torch.Tensor,
+        input_flatten: torch.Tensor,
+        input_spatial_shapes: torch.Tensor,
+        input_level_start_index: torch.Tensor,
+        input_padding_mask: torch.Tensor | None = None,
+    ) -> torch.Tensor:
+        value, locations, weights = self.sampling_inputs(
+            query, reference_points, input_flatten, input_spatial_shapes, input_padding_mask
+        )
+        out = MultiScaleDeformAttnFunction.apply(
+            value, input_spatial_shapes, input_level_start_index, locations, weights,
+            self.im2col_step,
+        )
+        return self.output_proj(out)
