@@ -1,0 +1,240 @@
+#!/usr/bin/env python3
+"""MSDeformAttn fwd+bwd throughput on MI355X: sampled points/s and fraction of the HBM roofline.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME] [--dist R|U]
+
+One step = one forward + one backward of the op over one batch of synthetic inputs that already
+sit in HBM.  N > 1 (launched by torch.distributed.run, one rank per GPU) shards the batch: every
+rank runs the same per-GPU workload on its own samples (weak scaling); the only collective is the
+all-reduce of a flat fp32 bucket the size of one MSDeformAttn layer's parameter gradients
+(RCCL), issued on a side stream and overlapped with the next step.
+
+Rank 0 prints ONE JSON line.
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import statistics
+import sys
+import time
+from pathlib import Path
+
+import torch
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+from unipercept_amd import harness  # noqa: E402
+
+HBM_PEAK = 8.0e12  # bytes/s, MI355X spec
+
+
+def cpu_baseline(threads: int) -> dict:
+    """The pure-PyTorch grid_sample oracle, timed on this host's cores on a bounded sample:
+    the CPU-reference workload (batch 1, 512x1024, 3 levels, 8 heads, 4 points, fp32)."""
+    from oracle import grid_sample_ref
+
+    w = harness.WORKLOADS["cpuref_512x1024_fp32_b1"]
+    torch.set_num_threads(threads)
+    value, shapes, lsi, loc, attn, grad_out = harness.synth_inputs(w, "cpu", seed=1234, dist="U")
+    levels = shapes.tolist()
+
+    def run():
+        v = value.requires_grad_(True)
+        lo = loc.requires_grad_(True)
+        a = attn.requires_grad_(True)
+        out = grid_sample_ref.deform_attn(v, levels, lo, a)
+        torch.autograd.grad(out, (v, lo, a), grad_out)
+
+    for _ in range(2):
+        run()
+    times = []
+    t_end = time.perf_counter() + 20.0
+    while len(times) < 10 and (time.perf_counter() < t_end or len(times) < 3):
+        t0 = time.perf_counter()
+        run()
+        times.append(time.perf_counter() - t0)
+    med = statistics.median(times)
+    pts = w.sampled_points()
+    return {
+        "value": pts / med,
+        "unit": "points/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": f"{w.name}: {pts} sampled points fwd+bwd, median of {len(times)} runs "
+        f"({med * 1e3:.1f} ms each), torch grid_sample formulation, {threads} threads",
+    }
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default=harness.HEADLINE, choices=sorted(harness.WORKLOADS))
+    ap.add_argument("--dist", default="R", choices=["R", "U"], help="sampling-location distribution")
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch override")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--fwd-only", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit(
+                f"--gpus {args.gpus} needs one rank per GPU: launch with "
+                f"`python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} "
+                "--master-addr 127.0.0.1 --master-port P bench.py ...`"
+            )
+        raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no GPU visible); there is no CPU fallback")
+
+    import torch.distributed as dist
+
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    from unipercept_amd.deform_attn import _ops  # loads libmsda.so (raises if missing)
+
+    w = harness.WORKLOADS[args.workload]
+    batch = args.batch or w.batch
+    value, shapes, lsi, loc, attn, grad_out = harness.synth_inputs(
+        w, device, batch=batch, seed=1234 + rank, dist=args.dist
+    )
+    fwd = torch.ops.unipercept.ms_deform_attn_fwd
+    bwd = torch.ops.unipercept.ms_deform_attn_bwd
+
+    bucket = None
+    comm_stream = None
+    if world > 1:
+        n_params = harness.layer_param_count(w.heads * w.head_dim, w.heads, w.n_levels, w.points)
+        bucket = harness.FlatGradBucket([n_params], device)
+        bucket.flat.normal_()
+        comm_stream = torch.cuda.Stream(device)
+
+    n_ev = args.steps
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(n_ev)]
+
+    def step(i: int | None) -> None:
+        if i is not None:
+            ev[i][0].record()
+        out = fwd(value, shapes, lsi, loc, attn, 0)
+        if i is not None:
+            ev[i][1].record()
+        if not args.fwd_only:
+            bwd(grad_out, value, shapes, lsi, loc, attn, 0)
+        if i is not None:
+            ev[i][2].record()
+        del out
+        if bucket is not None:
+            # the gradient bucket of this step is reduced while the next step computes
+            comm_stream.wait_stream(torch.cuda.current_stream(device))
+            with torch.cuda.stream(comm_stream):
+                bucket.all_reduce()
+
+    def fence() -> None:
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(device)
+
+    for _ in range(args.warmup):
+        step(None)
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    fwd_ms = statistics.mean(e[0].elapsed_time(e[1]) for e in ev)
+    bwd_ms = statistics.mean(e[1].elapsed_time(e[2]) for e in ev) if not args.fwd_only else 0.0
+
+    if rank == 0:
+        pts_per_gpu = w.sampled_points(batch)
+        ab = harness.algorithmic_bytes(w, batch)
+        ms_per_step = elapsed / args.steps * 1e3
+        value_pts = pts_per_gpu * world * args.steps / elapsed
+        dom, dom_ms, dom_bytes = (
+            ("forward", fwd_ms, ab["fwd"]) if args.fwd_only or fwd_ms > bwd_ms else ("backward", bwd_ms, ab["bwd"])
+        )
+        achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
+        step_bytes = ab["fwd"] if args.fwd_only else ab["fwd_bwd"]
+        line = {
+            "metric": "msdeformattn_fwd_bwd_sampled_points_per_sec"
+            if not args.fwd_only
+            else "msdeformattn_fwd_sampled_points_per_sec",
+            "value": value_pts,
+            "unit": "points/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": w.dtype,
+            "data": "synthetic",
+            "config": {
+                "workload": w.name,
+                "levels": [list(x) for x in w.levels],
+                "heads": w.heads,
+                "head_dim": w.head_dim,
+                "points": w.points,
+                "per_gpu_batch": batch,
+                "global_batch": batch * world,
+                "queries": w.positions,
+                "loc_dtype": w.loc_dtype or w.dtype,
+                "location_distribution": args.dist,
+                "sampled_points_per_gpu_step": pts_per_gpu,
+                "parallelism": f"dp{world}",
+                "collective": None
+                if world == 1
+                else f"all_reduce(sum)/world of one flat fp32 bucket of {bucket.flat.numel()} "
+                "layer-parameter gradients per step, RCCL, side stream",
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": f"msda_{dom} (all launches of the op, HIP events in the timed loop)",
+                "achieved": achieved,
+                "peak": HBM_PEAK / 1e9,
+                "unit": "GB/s",
+                "frac": achieved * 1e9 / HBM_PEAK,
+                "traffic": None,
+                "algorithmic_bytes_per_launch": dom_bytes,
+                "avg_launch_ms": dom_ms,
+            },
+            "phases": {
+                "fwd_ms": fwd_ms,
+                "bwd_ms": bwd_ms,
+                "fwd_points_per_s": pts_per_gpu / (fwd_ms * 1e-3),
+                "fwd_hbm_frac": ab["fwd"] / (fwd_ms * 1e-3) / HBM_PEAK,
+                "bwd_hbm_frac": ab["bwd"] / (bwd_ms * 1e-3) / HBM_PEAK if bwd_ms else None,
+                "step_hbm_frac": step_bytes / (ms_per_step * 1e-3) / HBM_PEAK,
+            },
+        }
+        if not args.no_cpu_baseline and world == 1:
+            threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
+            line["cpu_baseline"] = cpu_baseline(threads)
+        print(json.dumps(line), flush=True)
+
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
