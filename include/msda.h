@@ -57,6 +57,9 @@ enum {
   MSDA_FLAG_DETERMINISTIC = 1,
   /* Force the generic (any D, one lane per channel) kernels even where a tuned path exists. */
   MSDA_FLAG_GENERIC = 2,
+  /* Tuned path only: scatter grad_value with global fp32 atomics instead of the binned,
+   * LDS-accumulated path (for A/B measurements; much slower on MI355X). */
+  MSDA_FLAG_ATOMIC_SCATTER = 4,
 };
 
 /* Library ABI version (bumped when a signature changes). */
@@ -88,8 +91,9 @@ int msda_forward(const void* value, const int64_t* shapes_dev, const int64_t* ls
                  int L, int P, int dtype_val, int dtype_loc, int flags, void* hip_stream);
 
 /*
- * Scratch the backward needs, in bytes (0 when none).  Non-zero for 16-bit value dtypes
- * (an fp32 accumulation image of grad_value) and for the binned grad_value path.
+ * Scratch the backward needs, in bytes (0 when none).  The binned grad_value path keeps its
+ * scatter records (64 bytes per sampled point, worst case) and a tile directory there; the
+ * atomic paths need an fp32 accumulation image of grad_value for 16-bit value dtypes.
  */
 size_t msda_backward_workspace_bytes(int N, int S, int M, int D, int Lq, int L, int P,
                                      int dtype_val, int dtype_loc, int flags);

@@ -51,3 +51,94 @@ def test_golden(case, generic, monkeypatch):
         scale = np.abs(want).max() + 1e-30
         rel = np.abs(got.numpy() - want).max() / scale
         assert rel <= (2e-5 if dtype == torch.float32 else 1e-12), rel
+
+
+# ---------------------------------------------------------------------------------------------
+# Mid-size cases against the scalar C oracle (fp64 arithmetic on the same, already rounded inputs)
+# ---------------------------------------------------------------------------------------------
+def _oracle64(value, shapes, loc, attn, grad_out):
+    from oracle import cpu as oracle_cpu
+
+    v = value.detach().cpu().double().numpy()
+    lo = loc.detach().cpu().double().numpy()
+    a = attn.detach().cpu().double().numpy()
+    go = grad_out.detach().cpu().double().numpy()
+    sh = shapes.cpu().numpy()
+    out = oracle_cpu.forward(v, sh, lo, a)
+    gv, gl, ga = oracle_cpu.backward(go, v, sh, lo, a)
+    return out, gv, gl, ga
+
+
+def _hip(value, shapes, lsi, loc, attn, grad_out):
+    from unipercept_amd.deform_attn import MultiScaleDeformAttnFunction
+
+    v = value.clone().requires_grad_(True)
+    lo = loc.clone().requires_grad_(True)
+    a = attn.clone().requires_grad_(True)
+    out = MultiScaleDeformAttnFunction.apply(v, shapes, lsi, lo, a, 64)
+    out.backward(grad_out)
+    return tuple(t.detach().cpu().double().numpy() for t in (out, v.grad, lo.grad, a.grad))
+
+
+MID = {
+    # name: (n, m, d, lq, levels, p)
+    "enc_L3P4": (2, 8, 32, None, [(32, 64), (16, 32), (8, 16)], 4),
+    "enc_L4P4": (1, 8, 32, None, [(32, 32), (16, 16), (8, 8), (4, 4)], 4),
+    "enc_L4P8": (1, 8, 32, None, [(16, 32), (8, 16), (4, 8), (2, 4)], 8),
+    "dec_q300": (2, 8, 32, 300, [(32, 64), (16, 32), (8, 16)], 4),
+    "heads3_d64": (2, 3, 64, 777, [(20, 30), (10, 15), (5, 8)], 4),
+    "d16_ragged": (1, 5, 16, 515, [(17, 23), (9, 12), (1, 7)], 3),
+}
+
+
+@pytest.mark.parametrize("scatter", ["binned", "atomic"])
+@pytest.mark.parametrize("case", sorted(MID))
+def test_tuned_f32_vs_oracle(case, scatter, monkeypatch):
+    if scatter == "atomic":
+        monkeypatch.setenv("MSDA_ATOMIC_SCATTER", "1")
+    n, m, d, lq, levels, p = MID[case]
+    value, shapes, lsi, loc, attn, grad_out = make_inputs(
+        n, m, d, lq, levels, p, dtype=torch.float32, seed=11, device="cuda"
+    )
+    value = value * 100  # O(1) values: a harder test of the absolute tolerances
+    want = _oracle64(value, shapes, loc, attn, grad_out)
+    got = _hip(value, shapes, lsi, loc, attn, grad_out)
+    assert np.abs(got[0] - want[0]).max() <= FWD_ATOL_F32
+    for g, w_ in zip(got[1:], want[1:]):
+        assert np.abs(g - w_).max() <= BWD_ATOL_F32
+
+
+# bf16: 8 significand bits.  Inputs are rounded to bf16 first and the fp64 oracle is fed those
+# rounded values, so what is measured is the kernel's own error: fp32 accumulation plus one
+# rounding of each result to bf16 (relative 2^-9).  Stated tolerance: max-abs error <= 2^-7 of
+# the tensor's max-abs value (grad_loc: 2^-6, it multiplies two rounded quantities by W or H).
+@pytest.mark.parametrize("loc_f32", [False, True], ids=["loc_bf16", "loc_f32"])
+@pytest.mark.parametrize("case", ["enc_L3P4", "enc_L4P8", "heads3_d64"])
+def test_tuned_bf16_vs_oracle(case, loc_f32):
+    n, m, d, lq, levels, p = MID[case]
+    value, shapes, lsi, loc, attn, grad_out = make_inputs(
+        n, m, d, lq, levels, p, dtype=torch.float32, seed=5, device="cuda"
+    )
+    value = (value * 100).bfloat16()
+    grad_out = grad_out.bfloat16()
+    if not loc_f32:
+        loc, attn = loc.bfloat16(), attn.bfloat16()
+    want = _oracle64(value, shapes, loc, attn, grad_out)
+    got = _hip(value, shapes, lsi, loc, attn, grad_out)
+    for name, g, w_, tol in zip(
+        ("out", "grad_value", "grad_loc", "grad_attn"), got, want, (2**-7, 2**-7, 2**-6, 2**-7)
+    ):
+        err = np.abs(g - w_).max() / (np.abs(w_).max() + 1e-30)
+        assert err <= tol, (name, err)
+
+
+def test_fp16_generic_and_tuned():
+    n, m, d, lq, levels, p = MID["dec_q300"]
+    value, shapes, lsi, loc, attn, grad_out = make_inputs(
+        n, m, d, lq, levels, p, dtype=torch.float32, seed=3, device="cuda"
+    )
+    value, grad_out = (value * 100).half(), grad_out.half()
+    want = _oracle64(value, shapes, loc, attn, grad_out)
+    got = _hip(value, shapes, lsi, loc, attn, grad_out)  # fp16 value, fp32 loc/attn
+    for g, w_ in zip(got, want):
+        assert np.abs(g - w_).max() / (np.abs(w_).max() + 1e-30) <= 2**-9

@@ -16,6 +16,7 @@ ABI_VERSION = 1
 F32, F64, BF16, F16 = 0, 1, 2, 3
 FLAG_DETERMINISTIC = 1
 FLAG_GENERIC = 2
+FLAG_ATOMIC_SCATTER = 4
 
 # every symbol include/msda.h declares
 EXPORTS = (

@@ -201,7 +201,8 @@ size_t msda_backward_workspace_bytes(int N, int S, int M, int D, int Lq, int L, 
   if (check_common(N, S, M, D, Lq, L, P, dtype_val, dtype_loc) != MSDA_OK) return 0;
   if (flags & MSDA_FLAG_DETERMINISTIC) return 0;
   if (!(flags & MSDA_FLAG_GENERIC)) {
-    const int64_t t = tuned_backward_workspace_bytes(N, S, M, D, Lq, L, P, dtype_val, dtype_loc);
+    const int64_t t = tuned_backward_workspace_bytes(N, S, M, D, Lq, L, P, dtype_val, dtype_loc,
+                                                     !(flags & MSDA_FLAG_ATOMIC_SCATTER));
     if (t >= 0) return static_cast<size_t>(t);
   }
   if (needs_f32_image(dtype_val)) return static_cast<size_t>(N) * S * M * D * sizeof(float);
@@ -234,7 +235,7 @@ int msda_backward(const void* grad_out, const void* value, const int64_t* shapes
   if (!det && !(flags & MSDA_FLAG_GENERIC)) {
     const int t = tuned_backward(grad_out, value, shapes_dev, lsi_dev, loc, attn, grad_value,
                                  grad_loc, grad_attn, workspace, N, S, M, D, Lq, L, P, dtype_val,
-                                 dtype_loc, stream);
+                                 dtype_loc, !(flags & MSDA_FLAG_ATOMIC_SCATTER), stream);
     if (t != kNotTuned) return t;
   }
 #define MSDA_BWD(VT, LT, GT)                                                                  \

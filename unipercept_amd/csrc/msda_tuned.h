@@ -1,26 +1,34 @@
 // Tuned MSDeformAttn kernels for gfx950: head dims that split into 16-byte lane chunks.
 //
-// Work decomposition (forward and the query-side half of the backward):
+// Work decomposition shared by the forward and the query side of the backward:
 //   * a group of G lanes owns one (batch, query, head) triple; each lane holds CPL consecutive
 //     channels = one 16-byte chunk (CPL = 4 for fp32, 8 for bf16/fp16), so D = G * CPL and one
-//     bilinear corner of one head is a single contiguous D*e-byte segment fetched by G lanes
-//     with one global_load_dwordx4 each;
-//   * a 256-thread workgroup owns 256/G consecutive triples of one batch element.  Phase 1: all
-//     256 threads read the group's sampling locations and attention weights with coalesced
-//     loads, turn every point into {4 attention-scaled corner weights, 4 byte offsets} once,
-//     and stage that in LDS.  Phase 2: each group walks its points, broadcasting the staged
-//     record to its G lanes with two ds_read_b128, and gathers the corners.
-//   Per-point scalar work (floor, bounds, weights) is therefore done once per point instead of
-//   once per channel lane, and the value gather is issued as full 16-byte-per-lane loads.
+//     bilinear corner of one head is a single contiguous D*e-byte segment (one 128-byte line for
+//     fp32 D = 32) fetched by G lanes with one global_load_dwordx4 each;
+//   * a 256-thread workgroup owns consecutive queries of ONE head of one batch element, and the
+//     head is blockIdx.x % M: workgroups that share an XCD (equal blockIdx % 8) then gather from
+//     the same head's slab, which keeps the sliding window of that slab inside the XCD's L2;
+//   * phase 1: all 256 threads read the chunk's sampling locations and attention weights, turn
+//     every point into {4 attention-scaled corner weights, 4 byte offsets} once, and stage that
+//     in LDS; phase 2: each group walks its points, broadcasting the staged record to its G
+//     lanes with ds_read_b128, and gathers the corners.
+//
+// Backward grad_value (the scatter) avoids global float atomics, which run at the memory side
+// at ~1.3 TB/s of added bytes on MI355X.  The query-side kernel appends one 16-byte record per
+// (point, destination tile) to a per-workgroup region, grouped by tile, and publishes a
+// directory; a second kernel owns one destination tile (TS consecutive positions of one head)
+// per workgroup, accumulates the tile in LDS (no float atomics there either) and stores it once.
 #pragma once
 
 #include <initializer_list>
+#include <type_traits>
 
 #include "msda_common.h"
 
 namespace msda {
 
 constexpr int kNotTuned = INT32_MIN;
+constexpr int kMaxLevelsTuned = 16;
 
 template <typename VT>
 struct Chunk;  // 16 bytes of VT as CPL floats
@@ -52,7 +60,8 @@ struct Chunk<bf16_t> {
   __device__ __forceinline__ static void store(void* p, const float (&v)[8]) {
     uint32_t w[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) w[i] = f32_to_bf16_bits(v[2 * i]) | (f32_to_bf16_bits(v[2 * i + 1]) << 16);
+    for (int i = 0; i < 4; ++i)
+      w[i] = f32_to_bf16_bits(v[2 * i]) | (f32_to_bf16_bits(v[2 * i + 1]) << 16);
     *static_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
   }
 };
@@ -74,6 +83,23 @@ struct Chunk<f16_t> {
   }
 };
 
+struct LevelInfo {
+  int H, W, start;
+};
+
+// A level whose extent does not fit inside [0, S) gets H = W = 0: no address derived from it can
+// leave the value tensor, and its points contribute nothing.
+__device__ __forceinline__ LevelInfo load_level(const int64_t* __restrict__ shapes,
+                                                const int64_t* __restrict__ lsi, int l, int S) {
+  const int64_t h = shapes[2 * l], w = shapes[2 * l + 1], st = lsi[l];
+  const bool ok = h > 0 && w > 0 && st >= 0 && h <= S && w <= S && h * w <= S && st + h * w <= S;
+  LevelInfo r;
+  r.H = ok ? static_cast<int>(h) : 0;
+  r.W = ok ? static_cast<int>(w) : 0;
+  r.start = ok ? static_cast<int>(st) : 0;
+  return r;
+}
+
 // One staged sampling point occupies 2 (forward) or 3 (backward) 16-byte LDS slots:
 //   slot 0: the four corner weights, multiplied by the attention weight, 0 for a corner outside
 //           the level;
@@ -81,55 +107,102 @@ struct Chunk<f16_t> {
 //           included, lane offset not); they are multiples of 16, and bit 0 is set when the
 //           corner lies inside the level;
 //   slot 2: (backward only) {lx, ly, attn * W, attn * H}, lx/ly being the fractional parts.
-// LDS stride (in slots) between the point lists of consecutive groups is odd, so the 8 or 16
-// groups of a wave read from disjoint banks.
+// The LDS stride (in slots) between the point lists of consecutive groups is odd, so the groups
+// of a wave read from disjoint banks.
 __host__ __device__ constexpr int group_stride_slots(int LP, int slots) { return (slots * LP) | 1; }
 
-template <typename LT, int SLOTS>
-__device__ __forceinline__ void stage_points(const int64_t* __restrict__ shapes,
-                                             const int64_t* __restrict__ lsi,
-                                             const LT* __restrict__ loc_blk,
-                                             const LT* __restrict__ attn_blk, uint4* lds,
-                                             int groups_here, int first_group_m, int S, int M,
-                                             int D, int L, int P, int esize) {
-  // loc_blk / attn_blk point at the first point of the block's first group
-  const int LP = L * P;
-  const int npts = groups_here * LP;
+// One scatter record (16 bytes): what the tile kernel needs to redo the footprint of a point.
+//   x = query index | level << 28, y = attention weight, z/w = normalised location (x, y) as f32
+constexpr uint32_t kRecInvalid = 0xffffffffu;
+
+// Distinct destination tiles of a footprint (at most 4), written to t0..t3; returns the count.
+__device__ __forceinline__ int footprint_tiles(const Footprint<float>& f, int start, int ts_shift,
+                                               uint32_t (&tiles)[4]) {
+  uint32_t t[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) t[k] = static_cast<uint32_t>(start + f.pix[k]) >> ts_shift;
+  // keep corner k when it is valid and no earlier valid corner has the same tile
+  const bool keep0 = f.valid[0];
+  const bool keep1 = f.valid[1] && !(f.valid[0] && t[0] == t[1]);
+  const bool keep2 = f.valid[2] && !(f.valid[0] && t[0] == t[2]) && !(f.valid[1] && t[1] == t[2]);
+  const bool keep3 = f.valid[3] && !(f.valid[0] && t[0] == t[3]) && !(f.valid[1] && t[1] == t[3]) &&
+                     !(f.valid[2] && t[2] == t[3]);
+  const bool keep[4] = {keep0, keep1, keep2, keep3};
+  int n = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    // compact without dynamic indexing
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (keep[k] && j == n) tiles[j] = t[k];
+    n += keep[k] ? 1 : 0;
+  }
+  return n;
+}
+
+struct EmitCtx {
+  uint4* records;      // this workgroup's record region
+  uint32_t* tile_off;  // LDS: exclusive prefix of records per tile inside the region
+  uint32_t* tile_cnt;  // LDS: running rank per tile
+  int ts_shift;
+};
+
+// Stages the points of `nq` consecutive queries of head m (first query q_first) into LDS.
+template <typename LT, int SLOTS, bool EMIT>
+__device__ __forceinline__ void stage_chunk(const LevelInfo* lv, const LT* __restrict__ loc,
+                                            const LT* __restrict__ attn, uint4* stage, int b,
+                                            int q_first, int nq, int m, int M, int Lq, int LP,
+                                            int P, uint32_t rowb, uint32_t headb,
+                                            const EmitCtx& emit) {
+  const int npts = nq * LP;
   const int stride = group_stride_slots(LP, SLOTS);
-  const uint32_t rowb = static_cast<uint32_t>(M) * D * esize;
   for (int t = threadIdx.x; t < npts; t += 256) {
     const int g = t / LP, i = t - g * LP, l = i / P;
-    const int64_t h = shapes[2 * l], w = shapes[2 * l + 1], st = lsi[l];
-    const bool ok = h > 0 && w > 0 && st >= 0 && h <= S && w <= S && h * w <= S && st + h * w <= S;
-    const int H = ok ? static_cast<int>(h) : 0, W = ok ? static_cast<int>(w) : 0;
-    const int start = ok ? static_cast<int>(st) : 0;
-    const float x = Elem<LT>::load(loc_blk + 2 * t);
-    const float y = Elem<LT>::load(loc_blk + 2 * t + 1);
-    const float a = Elem<LT>::load(attn_blk + t);
-    const Footprint<float> f = footprint<float>(x, y, H, W);
-    const int m = (first_group_m + g) % M;
-    const uint32_t headb = static_cast<uint32_t>(m) * D * esize;
+    const LevelInfo L_ = lv[l];
+    const int64_t idx = ((static_cast<int64_t>(b) * Lq + q_first + g) * M + m) * LP + i;
+    const float x = Elem<LT>::load(loc + 2 * idx);
+    const float y = Elem<LT>::load(loc + 2 * idx + 1);
+    const float a = Elem<LT>::load(attn + idx);
+    const Footprint<float> f = footprint<float>(x, y, L_.H, L_.W);
     uint4 wrec, orec;
     wrec.x = __float_as_uint(a * f.w[0]);
     wrec.y = __float_as_uint(a * f.w[1]);
     wrec.z = __float_as_uint(a * f.w[2]);
     wrec.w = __float_as_uint(a * f.w[3]);
-    orec.x = (static_cast<uint32_t>(start + f.pix[0]) * rowb + headb) | (f.valid[0] ? 1u : 0u);
-    orec.y = (static_cast<uint32_t>(start + f.pix[1]) * rowb + headb) | (f.valid[1] ? 1u : 0u);
-    orec.z = (static_cast<uint32_t>(start + f.pix[2]) * rowb + headb) | (f.valid[2] ? 1u : 0u);
-    orec.w = (static_cast<uint32_t>(start + f.pix[3]) * rowb + headb) | (f.valid[3] ? 1u : 0u);
-    uint4* dst = lds + g * stride + SLOTS * i;
+    orec.x = (static_cast<uint32_t>(L_.start + f.pix[0]) * rowb + headb) | (f.valid[0] ? 1u : 0u);
+    orec.y = (static_cast<uint32_t>(L_.start + f.pix[1]) * rowb + headb) | (f.valid[1] ? 1u : 0u);
+    orec.z = (static_cast<uint32_t>(L_.start + f.pix[2]) * rowb + headb) | (f.valid[2] ? 1u : 0u);
+    orec.w = (static_cast<uint32_t>(L_.start + f.pix[3]) * rowb + headb) | (f.valid[3] ? 1u : 0u);
+    uint4* dst = stage + g * stride + SLOTS * i;
     dst[0] = wrec;
     dst[1] = orec;
     if constexpr (SLOTS == 3) {
-      const float xs = x * static_cast<float>(W) - 0.5f, ys = y * static_cast<float>(H) - 0.5f;
+      const float xs = x * static_cast<float>(L_.W) - 0.5f, ys = y * static_cast<float>(L_.H) - 0.5f;
       const float lx = f.any ? xs - floorf(xs) : 0.f, ly = f.any ? ys - floorf(ys) : 0.f;
       uint4 frec;
       frec.x = __float_as_uint(lx);
       frec.y = __float_as_uint(ly);
-      frec.z = __float_as_uint(a * static_cast<float>(W));
-      frec.w = __float_as_uint(a * static_cast<float>(H));
+      frec.z = __float_as_uint(a * static_cast<float>(L_.W));
+      frec.w = __float_as_uint(a * static_cast<float>(L_.H));
       dst[2] = frec;
+    }
+    if constexpr (EMIT) {
+      if (f.any && a != 0.f) {
+        uint32_t tiles[4] = {0, 0, 0, 0};
+        const int n = footprint_tiles(f, L_.start, emit.ts_shift, tiles);
+        uint4 rec;
+        rec.x = static_cast<uint32_t>(q_first + g) | (static_cast<uint32_t>(l) << 28);
+        rec.y = __float_as_uint(a);
+        rec.z = __float_as_uint(x);
+        rec.w = __float_as_uint(y);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (j < n) {
+            const uint32_t rank = atomicAdd(&emit.tile_cnt[tiles[j]], 1u);
+            emit.records[emit.tile_off[tiles[j]] + rank] = rec;
+          }
+        }
+      }
     }
   }
 }
@@ -144,22 +217,25 @@ __global__ __launch_bounds__(256) void fwd_tuned_kernel(
     VT* __restrict__ out, int S, int M, int Lq, int L, int P) {
   constexpr int CPL = Chunk<VT>::kCPL;
   constexpr int D = G * CPL;
-  constexpr int GPB = 256 / G;  // groups per block
+  constexpr int GPB = 256 / G;  // queries per block
   extern __shared__ uint4 lds[];
+  __shared__ LevelInfo lv[kMaxLevelsTuned];
 
   const int LP = L * P;
   const int b = blockIdx.y;
-  const int groups_per_batch = Lq * M;
-  const int g0 = blockIdx.x * GPB;  // first group of this block inside the batch element
-  const int groups_here = min(GPB, groups_per_batch - g0);
-  const int64_t gbase = static_cast<int64_t>(b) * groups_per_batch + g0;
+  const int m = blockIdx.x % M;
+  const int q0 = (blockIdx.x / M) * GPB;
+  const int nq = min(GPB, Lq - q0);
+  if (threadIdx.x < L) lv[threadIdx.x] = load_level(shapes, lsi, threadIdx.x, S);
+  __syncthreads();
 
-  stage_points<LT, 2>(shapes, lsi, loc + gbase * LP * 2, attn + gbase * LP, lds, groups_here,
-                      g0 % M, S, M, D, L, P, static_cast<int>(sizeof(VT)));
+  const uint32_t rowb = static_cast<uint32_t>(M) * D * sizeof(VT);
+  const uint32_t headb = static_cast<uint32_t>(m) * D * sizeof(VT);
+  stage_chunk<LT, 2, false>(lv, loc, attn, lds, b, q0, nq, m, M, Lq, LP, P, rowb, headb, EmitCtx{});
   __syncthreads();
 
   const int g = threadIdx.x / G, lane = threadIdx.x % G;
-  if (g >= groups_here) return;
+  if (g >= nq) return;
   const char* vb = reinterpret_cast<const char*>(value) +
                    static_cast<int64_t>(b) * S * M * D * static_cast<int64_t>(sizeof(VT));
   const uint32_t lane_b = lane * 16;
@@ -183,107 +259,383 @@ __global__ __launch_bounds__(256) void fwd_tuned_kernel(
 #pragma unroll
       for (int c = 0; c < CPL; ++c) acc[c] = fmaf(w[k], v[k][c], acc[c]);
   }
-  Chunk<VT>::store(reinterpret_cast<char*>(out) + ((gbase + g) * D + lane * CPL) * sizeof(VT), acc);
+  const int64_t triple = (static_cast<int64_t>(b) * Lq + q0 + g) * M + m;
+  Chunk<VT>::store(reinterpret_cast<char*>(out) + (triple * D + lane * CPL) * sizeof(VT), acc);
 }
 
 // ---------------------------------------------------------------------------------------------
-// Backward, query side: grad_loc, grad_attn, and the grad_value scatter by fp32 atomics.
+// Backward, query side
 // ---------------------------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+  return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(
+                                           0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+
 template <int G>
 __device__ __forceinline__ float group_sum(float v) {
   // butterfly inside groups of G <= 16 lanes on the DPP path (no LDS traffic)
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
-  if constexpr (G >= 8)
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));  // row_half_mirror
-  if constexpr (G >= 16)
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));  // row_mirror
+  v = dpp_add<0xB1>(v);                         // quad_perm [1,0,3,2]
+  v = dpp_add<0x4E>(v);                         // quad_perm [2,3,0,1]
+  if constexpr (G >= 8) v = dpp_add<0x141>(v);   // row_half_mirror
+  if constexpr (G >= 16) v = dpp_add<0x140>(v);  // row_mirror
   return v;
 }
 
-template <typename VT, typename LT, int G>
-__global__ __launch_bounds__(256) void bwd_tuned_atomic_kernel(
+// Exclusive scan of data[0..n) in LDS by the whole 256-thread workgroup; returns the total.
+// tmp: 256 words of LDS.  Ends with a barrier.
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t* data, int n, uint32_t* tmp) {
+  const int per = (n + 255) / 256;
+  const int lo = min(static_cast<int>(threadIdx.x) * per, n), hi = min(lo + per, n);
+  uint32_t sum = 0;
+  for (int i = lo; i < hi; ++i) sum += data[i];
+  tmp[threadIdx.x] = sum;
+  __syncthreads();
+  // Hillis-Steele over the 256 partials
+  for (int s = 1; s < 256; s <<= 1) {
+    const uint32_t add = threadIdx.x >= static_cast<unsigned>(s) ? tmp[threadIdx.x - s] : 0u;
+    __syncthreads();
+    tmp[threadIdx.x] += add;
+    __syncthreads();
+  }
+  uint32_t run = tmp[threadIdx.x] - sum;  // exclusive prefix of this thread's segment
+  const uint32_t total = tmp[255];
+  for (int i = lo; i < hi; ++i) {
+    const uint32_t c = data[i];
+    data[i] = run;
+    run += c;
+  }
+  __syncthreads();
+  return total;
+}
+
+struct BinPlan {
+  int ts_shift;     // log2 of the tile size in positions
+  int n_tiles;      // ceil(S / TS)
+  int qb;           // queries per query-side workgroup
+  int n_qblocks;    // ceil(Lq / qb)
+  uint32_t region;  // records per workgroup region
+};
+
+// MODE 0: grad_loc / grad_attn + grad_value by global fp32 atomics into `gv_acc`
+// MODE 1: grad_loc / grad_attn + scatter records for the tile kernel
+template <typename VT, typename LT, int G, int MODE>
+__global__ __launch_bounds__(256) void bwd_query_kernel(
     const VT* __restrict__ grad_out, const VT* __restrict__ value,
     const int64_t* __restrict__ shapes, const int64_t* __restrict__ lsi,
-    const LT* __restrict__ loc, const LT* __restrict__ attn, float* __restrict__ grad_value_acc,
-    LT* __restrict__ grad_loc, LT* __restrict__ grad_attn, int S, int M, int Lq, int L, int P) {
+    const LT* __restrict__ loc, const LT* __restrict__ attn, LT* __restrict__ grad_loc,
+    LT* __restrict__ grad_attn, float* __restrict__ gv_acc, uint4* __restrict__ records,
+    uint2* __restrict__ dir, int S, int M, int Lq, int L, int P, BinPlan plan) {
   constexpr int CPL = Chunk<VT>::kCPL;
   constexpr int D = G * CPL;
   constexpr int GPB = 256 / G;
   extern __shared__ uint4 lds[];
+  __shared__ LevelInfo lv[kMaxLevelsTuned];
+  __shared__ uint32_t scan_tmp[256];
 
   const int LP = L * P;
   const int b = blockIdx.y;
-  const int groups_per_batch = Lq * M;
-  const int g0 = blockIdx.x * GPB;
-  const int groups_here = min(GPB, groups_per_batch - g0);
-  const int64_t gbase = static_cast<int64_t>(b) * groups_per_batch + g0;
-  const LT* loc_blk = loc + gbase * LP * 2;
-  const LT* attn_blk = attn + gbase * LP;
-
-  stage_points<LT, 3>(shapes, lsi, loc_blk, attn_blk, lds, groups_here, g0 % M, S, M, D, L, P,
-                      static_cast<int>(sizeof(VT)));
+  const int m = blockIdx.x % M;
+  const int qblock = blockIdx.x / M;
+  const int qb0 = qblock * plan.qb;
+  const int qb_n = min(plan.qb, Lq - qb0);
+  if (threadIdx.x < L) lv[threadIdx.x] = load_level(shapes, lsi, threadIdx.x, S);
   __syncthreads();
 
-  // lanes of groups past the end redo the last group (no writes) so that every DPP row is full
-  const int g = min(static_cast<int>(threadIdx.x) / G, groups_here - 1);
-  const bool live = static_cast<int>(threadIdx.x) / G < groups_here;
-  const int lane = threadIdx.x % G;
-  const int64_t slab = static_cast<int64_t>(b) * S * M * D;
-  const char* vb = reinterpret_cast<const char*>(value) + slab * static_cast<int64_t>(sizeof(VT));
-  float* gvb = grad_value_acc + slab;
-  const uint32_t lane_b = lane * 16;
-  const uint4* rec = lds + g * group_stride_slots(LP, 3);
+  const uint32_t rowb = static_cast<uint32_t>(M) * D * sizeof(VT);
+  const uint32_t headb = static_cast<uint32_t>(m) * D * sizeof(VT);
+  uint4* stage = lds;
+  const int stage_slots = GPB * group_stride_slots(LP, 3);
+  uint32_t* tile_cnt = reinterpret_cast<uint32_t*>(lds + stage_slots);
+  uint32_t* tile_off = tile_cnt + plan.n_tiles;
+  EmitCtx emit{};
 
-  float go[CPL];
-  Chunk<VT>::load(reinterpret_cast<const char*>(grad_out) +
-                      ((gbase + g) * D + lane * CPL) * sizeof(VT),
-                  go);
-
-  for (int i = 0; i < LP; ++i) {
-    const uint4 wr = rec[3 * i], orr = rec[3 * i + 1], fr = rec[3 * i + 2];
-    const float aw[4] = {__uint_as_float(wr.x), __uint_as_float(wr.y), __uint_as_float(wr.z),
-                         __uint_as_float(wr.w)};
-    const uint32_t oraw[4] = {orr.x, orr.y, orr.z, orr.w};
-    const float lx = __uint_as_float(fr.x), ly = __uint_as_float(fr.y);
-    const float aW = __uint_as_float(fr.z), aH = __uint_as_float(fr.w);
-    const float hx = 1.f - lx, hy = 1.f - ly;
-    float v[4][CPL];
-    uint32_t o[4];
+  if constexpr (MODE == 1) {
+    // ---- count the records of this workgroup per destination tile ----
+    for (int t = threadIdx.x; t < plan.n_tiles; t += 256) tile_cnt[t] = 0;
+    __syncthreads();
+    const int npts = qb_n * LP;
+    for (int t = threadIdx.x; t < npts; t += 256) {
+      const int g = t / LP, i = t - g * LP, l = i / P;
+      const LevelInfo L_ = lv[l];
+      const int64_t idx = ((static_cast<int64_t>(b) * Lq + qb0 + g) * M + m) * LP + i;
+      const float x = Elem<LT>::load(loc + 2 * idx);
+      const float y = Elem<LT>::load(loc + 2 * idx + 1);
+      const float a = Elem<LT>::load(attn + idx);
+      const Footprint<float> f = footprint<float>(x, y, L_.H, L_.W);
+      if (f.any && a != 0.f) {
+        uint32_t tiles[4] = {0, 0, 0, 0};
+        const int n = footprint_tiles(f, L_.start, plan.ts_shift, tiles);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      o[k] = (oraw[k] & ~15u) + lane_b;
-      Chunk<VT>::load(vb + o[k], v[k]);
-    }
-    float dot[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      float d = 0.f;
-#pragma unroll
-      for (int c = 0; c < CPL; ++c) d = fmaf(go[c], v[k][c], d);
-      dot[k] = (oraw[k] & 1u) ? d : 0.f;  // a corner outside the level contributes nothing
-    }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      if (live && aw[k] != 0.f) {
-        float* dst = gvb + o[k] / sizeof(VT);
-#pragma unroll
-        for (int c = 0; c < CPL; ++c) atomicAdd(dst + c, aw[k] * go[c]);
+        for (int j = 0; j < 4; ++j)
+          if (j < n) atomicAdd(&tile_cnt[tiles[j]], 1u);
       }
     }
-    // with w = {hy*hx, hy*lx, ly*hx, ly*lx}, dw/dx = {-hy, hy, -ly, ly}, dw/dy = {-hx, -lx, hx, lx}
-    float sv = hy * fmaf(hx, dot[0], lx * dot[1]) + ly * fmaf(hx, dot[2], lx * dot[3]);
-    float sx = fmaf(hy, dot[1] - dot[0], ly * (dot[3] - dot[2]));
-    float sy = fmaf(hx, dot[2] - dot[0], lx * (dot[3] - dot[1]));
-    sv = group_sum<G>(sv);
-    sx = group_sum<G>(sx);
-    sy = group_sum<G>(sy);
-    if (lane == 0 && live) {
-      const int64_t gi = (gbase + g) * LP + i;
-      Elem<LT>::store(grad_attn + gi, sv);
-      Elem<LT>::store(grad_loc + 2 * gi, aW * sx);
-      Elem<LT>::store(grad_loc + 2 * gi + 1, aH * sy);
+    __syncthreads();
+    // directory row of this workgroup: (offset, count) per tile, then ranks restart from 0
+    const int64_t slab = static_cast<int64_t>(b) * M + m;
+    uint2* dir_row = dir + (slab * plan.n_qblocks + qblock) * plan.n_tiles;
+    for (int t = threadIdx.x; t < plan.n_tiles; t += 256) tile_off[t] = tile_cnt[t];
+    __syncthreads();
+    block_exclusive_scan(tile_off, plan.n_tiles, scan_tmp);
+    for (int t = threadIdx.x; t < plan.n_tiles; t += 256) {
+      dir_row[t] = make_uint2(tile_off[t], tile_cnt[t]);
+      tile_cnt[t] = 0;
     }
+    emit.records = records + (slab * plan.n_qblocks + qblock) * static_cast<int64_t>(plan.region);
+    emit.tile_off = tile_off;
+    emit.tile_cnt = tile_cnt;
+    emit.ts_shift = plan.ts_shift;
+    __syncthreads();
+  }
+
+  const int g = threadIdx.x / G, lane = threadIdx.x % G;
+  const int64_t slab_elems = static_cast<int64_t>(b) * S * M * D;
+  const char* vb = reinterpret_cast<const char*>(value) + slab_elems * static_cast<int64_t>(sizeof(VT));
+  const uint32_t lane_b = lane * 16;
+
+  for (int c0 = 0; c0 < qb_n; c0 += GPB) {
+    const int nq = min(GPB, qb_n - c0);
+    stage_chunk<LT, 3, MODE == 1>(lv, loc, attn, stage, b, qb0 + c0, nq, m, M, Lq, LP, P, rowb,
+                                  headb, emit);
+    __syncthreads();
+    // lanes of groups past the end redo the last group (no writes) so that every DPP row is full
+    const bool live = g < nq;
+    const int gg = live ? g : nq - 1;
+    const uint4* r = stage + gg * group_stride_slots(LP, 3);
+    const int64_t triple = (static_cast<int64_t>(b) * Lq + qb0 + c0 + gg) * M + m;
+    float go[CPL];
+    Chunk<VT>::load(reinterpret_cast<const char*>(grad_out) + (triple * D + lane * CPL) * sizeof(VT), go);
+
+    for (int i = 0; i < LP; ++i) {
+      const uint4 wr = r[3 * i], orr = r[3 * i + 1], fr = r[3 * i + 2];
+      const uint32_t oraw[4] = {orr.x, orr.y, orr.z, orr.w};
+      const float lx = __uint_as_float(fr.x), ly = __uint_as_float(fr.y);
+      const float aW = __uint_as_float(fr.z), aH = __uint_as_float(fr.w);
+      const float hx = 1.f - lx, hy = 1.f - ly;
+      float v[4][CPL];
+      uint32_t o[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        o[k] = (oraw[k] & ~15u) + lane_b;
+        Chunk<VT>::load(vb + o[k], v[k]);
+      }
+      float dot[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float d = 0.f;
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) d = fmaf(go[c], v[k][c], d);
+        dot[k] = (oraw[k] & 1u) ? d : 0.f;  // a corner outside the level contributes nothing
+      }
+      if constexpr (MODE == 0) {
+        const float aw[4] = {__uint_as_float(wr.x), __uint_as_float(wr.y), __uint_as_float(wr.z),
+                             __uint_as_float(wr.w)};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          if (live && aw[k] != 0.f) {
+            float* dst = gv_acc + slab_elems + o[k] / sizeof(VT);
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) atomicAdd(dst + c, aw[k] * go[c]);
+          }
+        }
+      } else {
+        (void)wr;
+      }
+      // w = {hy*hx, hy*lx, ly*hx, ly*lx}; dw/dx = {-hy, hy, -ly, ly}; dw/dy = {-hx, -lx, hx, lx}
+      float sv = hy * fmaf(hx, dot[0], lx * dot[1]) + ly * fmaf(hx, dot[2], lx * dot[3]);
+      float sx = fmaf(hy, dot[1] - dot[0], ly * (dot[3] - dot[2]));
+      float sy = fmaf(hx, dot[2] - dot[0], lx * (dot[3] - dot[1]));
+      sv = group_sum<G>(sv);
+      sx = group_sum<G>(sx);
+      sy = group_sum<G>(sy);
+      if (lane == 0 && live) {
+        const int64_t gi = triple * LP + i;
+        Elem<LT>::store(grad_attn + gi, sv);
+        Elem<LT>::store(grad_loc + 2 * gi, aW * sx);
+        Elem<LT>::store(grad_loc + 2 * gi + 1, aH * sy);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Backward, destination side: one workgroup per (batch, head, tile of TS positions)
+//
+// ds_add_f32 runs at ~0.3 lanes/clk/CU on gfx950 (measured; ds_add_u32 does ~12), so the tile is
+// NOT accumulated with LDS float atomics.  Instead each slice of 256 records is bucketed by
+// destination position with integer LDS atomics (count, scan, fill), the slice's grad_out rows
+// are staged in LDS once, and every group of G lanes then owns TS/(256/G) consecutive positions
+// and adds its bucket entries into the LDS tile with plain read-modify-write.
+// ---------------------------------------------------------------------------------------------
+template <typename VT, int G>
+__global__ __launch_bounds__(256) void bwd_tile_kernel(
+    const VT* __restrict__ grad_out, const int64_t* __restrict__ shapes,
+    const int64_t* __restrict__ lsi, const uint4* __restrict__ records,
+    const uint2* __restrict__ dir, VT* __restrict__ grad_value, int S, int M, int Lq, int L,
+    BinPlan plan) {
+  constexpr int CPL = Chunk<VT>::kCPL;
+  constexpr int D = G * CPL;
+  constexpr int GPB = 256 / G;   // groups per workgroup
+  constexpr int R = 256;         // records per slice (one per thread)
+  constexpr int SPG = R / GPB;   // record slots staged per group (= G)
+  extern __shared__ uint4 lds[];
+  __shared__ LevelInfo lv[kMaxLevelsTuned];
+  __shared__ uint32_t scan_tmp[256];
+  __shared__ uint32_t wsum[4];
+
+  const int TS = 1 << plan.ts_shift;
+  const int PPG = TS / GPB;  // positions owned by one group
+  float* acc = reinterpret_cast<float*>(lds);                     // TS * D floats
+  float* gstage = acc + TS * D;                                   // R * D floats
+  uint2* entries = reinterpret_cast<uint2*>(gstage + R * D);      // 4 * R entries
+  uint32_t* cnt = reinterpret_cast<uint32_t*>(entries + 4 * R);   // TS
+  uint32_t* start = cnt + TS;                                     // TS + 1
+  uint32_t* cursor = start + TS + 1;                              // TS
+  uint32_t* pre = cursor + TS;                                    // n_qblocks + 1
+  uint32_t* offs = pre + plan.n_qblocks + 1;                      // n_qblocks
+
+  const int b = blockIdx.y;
+  const int m = blockIdx.x % M;
+  const int tile = plan.n_tiles - 1 - blockIdx.x / M;  // coarse (record-heavy) levels first
+  const int64_t slab = static_cast<int64_t>(b) * M + m;
+  if (threadIdx.x < L) lv[threadIdx.x] = load_level(shapes, lsi, threadIdx.x, S);
+  for (int i = threadIdx.x; i < TS * D; i += 256) acc[i] = 0.f;
+  for (int i = threadIdx.x; i < TS; i += 256) cnt[i] = 0;
+  for (int qbk = threadIdx.x; qbk < plan.n_qblocks; qbk += 256) {
+    const uint2 e = dir[(slab * plan.n_qblocks + qbk) * plan.n_tiles + tile];
+    offs[qbk] = e.x;
+    pre[qbk] = e.y;
+  }
+  if (threadIdx.x == 0) pre[plan.n_qblocks] = 0;
+  __syncthreads();
+  const uint32_t total = block_exclusive_scan(pre, plan.n_qblocks + 1, scan_tmp);
+
+  const int g = threadIdx.x / G, lane = threadIdx.x % G;
+  const int wave = threadIdx.x >> 6, wlane = threadIdx.x & 63;
+  const uint4* slab_records = records + slab * plan.n_qblocks * static_cast<int64_t>(plan.region);
+  const char* go_base = reinterpret_cast<const char*>(grad_out);
+  const uint32_t tile_u = static_cast<uint32_t>(tile);
+
+  for (uint32_t base = 0; base < total; base += R) {
+    // ---- A: one record per thread ----
+    const uint32_t r = base + threadIdx.x;
+    uint4 rec = make_uint4(kRecInvalid, 0, 0, 0);
+    if (r < total) {
+      int lo = 0, hi = plan.n_qblocks;  // largest qbk with pre[qbk] <= r
+      while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (pre[mid] <= r) lo = mid; else hi = mid;
+      }
+      rec = slab_records[static_cast<int64_t>(lo) * plan.region + offs[lo] + (r - pre[lo])];
+    }
+    const bool have = rec.x != kRecInvalid;
+    // ---- B: grad_out rows of this group's record slots, straight into registers ----
+    float go[SPG][CPL];
+#pragma unroll
+    for (int k = 0; k < SPG; ++k) {
+      const uint32_t qk = __shfl(rec.x, k, G);  // record slot g*SPG + k lives in lane k of the group
+      if (qk != kRecInvalid) {
+        const int64_t triple = (static_cast<int64_t>(b) * Lq + (qk & 0x0fffffffu)) * M + m;
+        Chunk<VT>::load(go_base + (triple * D + lane * CPL) * sizeof(VT), go[k]);
+      } else {
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) go[k][c] = 0.f;
+      }
+    }
+    // ---- C: footprint of the thread's own record, count its in-tile corners per position ----
+    uint32_t loc_pix[4];
+    float loc_w[4];
+    bool in_tile[4] = {false, false, false, false};
+    if (have) {
+      const LevelInfo L_ = lv[rec.x >> 28];
+      const float a = __uint_as_float(rec.y);
+      const Footprint<float> f =
+          footprint<float>(__uint_as_float(rec.z), __uint_as_float(rec.w), L_.H, L_.W);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const uint32_t pos = static_cast<uint32_t>(L_.start + f.pix[k]);
+        in_tile[k] = f.valid[k] && (pos >> plan.ts_shift) == tile_u;
+        loc_pix[k] = pos & (TS - 1);
+        loc_w[k] = a * f.w[k];
+        if (in_tile[k]) atomicAdd(&cnt[loc_pix[k]], 1u);
+      }
+    }
+    __syncthreads();
+    // ---- D: exclusive scan of the per-position counts (TS <= 256: one per thread) ----
+    {
+      const uint32_t c = threadIdx.x < static_cast<unsigned>(TS) ? cnt[threadIdx.x] : 0u;
+      uint32_t x = c;
+#pragma unroll
+      for (int sft = 1; sft < 64; sft <<= 1) {
+        const uint32_t y = __shfl_up(x, sft, 64);
+        if (wlane >= sft) x += y;
+      }
+      if (wlane == 63) wsum[wave] = x;
+      __syncthreads();
+      uint32_t off = 0;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) off += (w < wave) ? wsum[w] : 0u;
+      if (threadIdx.x < static_cast<unsigned>(TS)) {
+        start[threadIdx.x] = off + x - c;
+        cursor[threadIdx.x] = off + x - c;
+        cnt[threadIdx.x] = 0;  // ready for the next slice
+      }
+      if (threadIdx.x == 255) start[TS] = off + x;
+    }
+    __syncthreads();
+    // ---- E: fill the buckets; stage the grad_out rows ----
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (in_tile[k]) {
+        const uint32_t pos = atomicAdd(&cursor[loc_pix[k]], 1u);
+        entries[pos] = make_uint2(threadIdx.x | (loc_pix[k] << 16), __float_as_uint(loc_w[k]));
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < SPG; ++k) {
+      float* dst = gstage + (g * SPG + k) * D + lane * CPL;
+#pragma unroll
+      for (int c = 0; c < CPL; c += 4)
+        *reinterpret_cast<float4*>(dst + c) = make_float4(go[k][c], go[k][c + 1], go[k][c + 2], go[k][c + 3]);
+    }
+    __syncthreads();
+    // ---- F: each group adds the entries of the positions it owns ----
+    {
+      const uint32_t e0 = start[min(g * PPG, TS)], e1 = start[min((g + 1) * PPG, TS)];
+      for (uint32_t e = e0; e < e1; ++e) {
+        const uint2 ent = entries[e];
+        const float w = __uint_as_float(ent.y);
+        const float* row = gstage + (ent.x & 0xffffu) * D + lane * CPL;
+        float* dst = acc + (ent.x >> 16) * D + lane * CPL;
+#pragma unroll
+        for (int c = 0; c < CPL; c += 4) {
+          const float4 rv = *reinterpret_cast<const float4*>(row + c);
+          float4 av = *reinterpret_cast<float4*>(dst + c);
+          av.x = fmaf(w, rv.x, av.x);
+          av.y = fmaf(w, rv.y, av.y);
+          av.z = fmaf(w, rv.z, av.z);
+          av.w = fmaf(w, rv.w, av.w);
+          *reinterpret_cast<float4*>(dst + c) = av;
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  // store the tile: one group per position
+  const int64_t row_elems = static_cast<int64_t>(M) * D;
+  for (int local = g; local < TS; local += GPB) {
+    const int64_t pos = static_cast<int64_t>(tile) * TS + local;
+    if (pos >= S) break;
+    float v[CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) v[c] = acc[local * D + lane * CPL + c];
+    Chunk<VT>::store(reinterpret_cast<char*>(grad_value) +
+                         (((static_cast<int64_t>(b) * S + pos) * row_elems) + m * D + lane * CPL) *
+                             sizeof(VT),
+                     v);
   }
 }
 
@@ -314,12 +666,14 @@ inline bool tuned_shape_ok(int N, int S, int M, int D, int Lq, int L, int P, int
   if (D % cpl) return false;
   const int G = D / cpl;
   if (G != 4 && G != 8 && G != 16) return false;
+  if (L > kMaxLevelsTuned) return false;
   const int esize = cpl == 4 ? 4 : 2;
   if (static_cast<int64_t>(S) * M * D * esize > static_cast<int64_t>(UINT32_MAX)) return false;
   if (N > 65535) return false;
-  if (static_cast<int64_t>(Lq) * M > INT32_MAX) return false;
-  // LDS: (256/G) groups * (2*L*P + 1) slots * 16 B
-  if (static_cast<int64_t>(256 / G) * group_stride_slots(L * P, 3) * 16 > 64 * 1024) return false;
+  const int GPB = 256 / G;
+  if ((static_cast<int64_t>(Lq) + GPB - 1) / GPB * M > INT32_MAX) return false;
+  // LDS staging: (256/G) groups * (3*L*P | 1) slots * 16 B
+  if (static_cast<int64_t>(GPB) * group_stride_slots(L * P, 3) * 16 > 48 * 1024) return false;
   *G_out = G;
   return true;
 }
@@ -330,12 +684,40 @@ inline bool all_aligned16(std::initializer_list<const void*> ps) {
   return true;
 }
 
+// Binned grad_value plan; returns false when the shape is outside what the binned path handles
+// (very long sequences), in which case the fp32-atomic query kernel is used.
+inline bool make_bin_plan(int N, int S, int M, int D, int Lq, int L, int P, BinPlan* plan,
+                          size_t* dir_bytes, size_t* rec_bytes) {
+  if (D > 64) return false;                  // the LDS row stage of a slice is 256 * D * 4 B
+  const int ts_shift = D <= 32 ? 8 : 7;      // TS * D * 4 B = 32 KB of LDS
+  const int TS = 1 << ts_shift;
+  const int64_t n_tiles = (static_cast<int64_t>(S) + TS - 1) / TS;
+  const int qb = 256;
+  const int64_t n_qblocks = (static_cast<int64_t>(Lq) + qb - 1) / qb;
+  if (n_tiles > 2048 || n_qblocks > 2048 || Lq >= (1 << 28)) return false;
+  const int64_t slabs = static_cast<int64_t>(N) * M;
+  const int64_t dir_b = slabs * n_qblocks * n_tiles * 8;
+  if (dir_b > (static_cast<int64_t>(1) << 30)) return false;
+  // a point lands in at most 4 tiles: regions can never overflow
+  const int64_t region = static_cast<int64_t>(qb) * L * P * 4;
+  const int64_t rec_b = slabs * n_qblocks * region * 16;
+  if (n_tiles * M > INT32_MAX || n_qblocks * M > INT32_MAX) return false;
+  plan->ts_shift = ts_shift;
+  plan->n_tiles = static_cast<int>(n_tiles);
+  plan->qb = qb;
+  plan->n_qblocks = static_cast<int>(n_qblocks);
+  plan->region = static_cast<uint32_t>(region);
+  *dir_bytes = (static_cast<size_t>(dir_b) + 255) & ~static_cast<size_t>(255);
+  *rec_bytes = static_cast<size_t>(rec_b);
+  return true;
+}
+
 template <typename VT, typename LT>
 int tuned_forward_typed(const void* value, const int64_t* shapes, const int64_t* lsi,
                         const void* loc, const void* attn, void* out, int N, int S, int M, int Lq,
                         int L, int P, int G, hipStream_t stream) {
   const int GPB = 256 / G;
-  const dim3 grid((Lq * M + GPB - 1) / GPB, N);
+  const dim3 grid(static_cast<unsigned>((Lq + GPB - 1) / GPB) * M, N);
   const size_t lds = static_cast<size_t>(GPB) * group_stride_slots(L * P, 2) * 16;
 #define MSDA_TF(GG)                                                                             \
   hipLaunchKernelGGL((fwd_tuned_kernel<VT, LT, GG>), grid, dim3(256), lds, stream,              \
@@ -368,9 +750,13 @@ inline int tuned_forward(const void* value, const int64_t* shapes, const int64_t
 }
 
 inline int64_t tuned_backward_workspace_bytes(int N, int S, int M, int D, int Lq, int L, int P,
-                                              int dtype_val, int dtype_loc) {
+                                              int dtype_val, int dtype_loc, bool allow_binned) {
   int G;
   if (!tuned_shape_ok(N, S, M, D, Lq, L, P, dtype_val, dtype_loc, &G)) return -1;
+  BinPlan plan;
+  size_t dir_b, rec_b;
+  if (allow_binned && make_bin_plan(N, S, M, D, Lq, L, P, &plan, &dir_b, &rec_b))
+    return static_cast<int64_t>(dir_b + rec_b);
   if (dtype_val == 0) return 0;
   return static_cast<int64_t>(N) * S * M * D * 4;  // fp32 accumulation image of grad_value
 }
@@ -379,20 +765,62 @@ template <typename VT, typename LT>
 int tuned_backward_typed(const void* grad_out, const void* value, const int64_t* shapes,
                          const int64_t* lsi, const void* loc, const void* attn, void* grad_value,
                          void* grad_loc, void* grad_attn, void* workspace, int N, int S, int M,
-                         int D, int Lq, int L, int P, int G, hipStream_t stream) {
+                         int D, int Lq, int L, int P, int G, bool allow_binned,
+                         hipStream_t stream) {
   const int GPB = 256 / G;
-  const dim3 grid((Lq * M + GPB - 1) / GPB, N);
-  const size_t lds = static_cast<size_t>(GPB) * group_stride_slots(L * P, 3) * 16;
+  const int LP = L * P;
+  BinPlan plan{};
+  size_t dir_b = 0, rec_b = 0;
+  const bool binned = allow_binned && make_bin_plan(N, S, M, D, Lq, L, P, &plan, &dir_b, &rec_b);
+  hipError_t e;
+
+  if (binned) {
+    uint2* dir = static_cast<uint2*>(workspace);
+    uint4* records = reinterpret_cast<uint4*>(static_cast<char*>(workspace) + dir_b);
+    const dim3 qgrid(static_cast<unsigned>(plan.n_qblocks) * M, N);
+    const size_t qlds = static_cast<size_t>(GPB) * group_stride_slots(LP, 3) * 16 +
+                        static_cast<size_t>(plan.n_tiles) * 8;
+    const dim3 tgrid(static_cast<unsigned>(plan.n_tiles) * M, N);
+    const size_t TSz = static_cast<size_t>(1) << plan.ts_shift;
+    const size_t tlds = TSz * D * 4 + 256 * static_cast<size_t>(D) * 4 + 4 * 256 * 8 +
+                        (3 * TSz + 1) * 4 + (2 * static_cast<size_t>(plan.n_qblocks) + 1) * 4;
+#define MSDA_TB(GG)                                                                              \
+  hipLaunchKernelGGL((bwd_query_kernel<VT, LT, GG, 1>), qgrid, dim3(256), qlds, stream,          \
+                     static_cast<const VT*>(grad_out), static_cast<const VT*>(value), shapes,    \
+                     lsi, static_cast<const LT*>(loc), static_cast<const LT*>(attn),             \
+                     static_cast<LT*>(grad_loc), static_cast<LT*>(grad_attn),                    \
+                     static_cast<float*>(nullptr), records, dir, S, M, Lq, L, P, plan);          \
+  hipLaunchKernelGGL((bwd_tile_kernel<VT, GG>), tgrid, dim3(256), tlds, stream,                  \
+                     static_cast<const VT*>(grad_out), shapes, lsi, records, dir,                \
+                     static_cast<VT*>(grad_value), S, M, Lq, L, plan)
+    switch (G) {
+      case 4: MSDA_TB(4); break;
+      case 8: MSDA_TB(8); break;
+      default: MSDA_TB(16); break;
+    }
+#undef MSDA_TB
+    e = hipGetLastError();
+    return e == hipSuccess ? 0 : static_cast<int>(e);
+  }
+
+  // fp32-atomic fallback (very long sequences)
+  plan.qb = 256;
+  plan.n_qblocks = (Lq + plan.qb - 1) / plan.qb;
+  plan.n_tiles = 0;
+  const dim3 grid(static_cast<unsigned>(plan.n_qblocks) * M, N);
+  const size_t lds = static_cast<size_t>(GPB) * group_stride_slots(LP, 3) * 16;
   const int64_t total = static_cast<int64_t>(N) * S * M * D;
   constexpr bool kDirect = sizeof(VT) == 4;
   float* acc = kDirect ? static_cast<float*>(grad_value) : static_cast<float*>(workspace);
-  hipError_t e = hipMemsetAsync(acc, 0, static_cast<size_t>(total) * 4, stream);
+  e = hipMemsetAsync(acc, 0, static_cast<size_t>(total) * 4, stream);
   if (e != hipSuccess) return static_cast<int>(e);
 #define MSDA_TB(GG)                                                                              \
-  hipLaunchKernelGGL((bwd_tuned_atomic_kernel<VT, LT, GG>), grid, dim3(256), lds, stream,        \
+  hipLaunchKernelGGL((bwd_query_kernel<VT, LT, GG, 0>), grid, dim3(256), lds, stream,            \
                      static_cast<const VT*>(grad_out), static_cast<const VT*>(value), shapes,    \
-                     lsi, static_cast<const LT*>(loc), static_cast<const LT*>(attn), acc,        \
-                     static_cast<LT*>(grad_loc), static_cast<LT*>(grad_attn), S, M, Lq, L, P)
+                     lsi, static_cast<const LT*>(loc), static_cast<const LT*>(attn),             \
+                     static_cast<LT*>(grad_loc), static_cast<LT*>(grad_attn), acc,               \
+                     static_cast<uint4*>(nullptr), static_cast<uint2*>(nullptr), S, M, Lq, L, P, \
+                     plan)
   switch (G) {
     case 4: MSDA_TB(4); break;
     case 8: MSDA_TB(8); break;
@@ -404,9 +832,9 @@ int tuned_backward_typed(const void* grad_out, const void* value, const int64_t*
   if constexpr (!kDirect) {
     const int64_t total8 = total / 8;  // D is a multiple of 8 on this path
     const int64_t cb = (total8 + 255) / 256;
-    hipLaunchKernelGGL((convert_f32_image_kernel<VT>), dim3(static_cast<unsigned>(cb < 4096 ? cb : 4096)),
-                       dim3(256), 0, stream, static_cast<const float*>(workspace),
-                       static_cast<VT*>(grad_value), total8);
+    hipLaunchKernelGGL((convert_f32_image_kernel<VT>),
+                       dim3(static_cast<unsigned>(cb < 4096 ? cb : 4096)), dim3(256), 0, stream,
+                       static_cast<const float*>(workspace), static_cast<VT*>(grad_value), total8);
     e = hipGetLastError();
     if (e != hipSuccess) return static_cast<int>(e);
   }
@@ -417,13 +845,13 @@ inline int tuned_backward(const void* grad_out, const void* value, const int64_t
                           const int64_t* lsi, const void* loc, const void* attn, void* grad_value,
                           void* grad_loc, void* grad_attn, void* workspace, int N, int S, int M,
                           int D, int Lq, int L, int P, int dtype_val, int dtype_loc,
-                          hipStream_t stream) {
+                          bool allow_binned, hipStream_t stream) {
   int G;
   if (!tuned_shape_ok(N, S, M, D, Lq, L, P, dtype_val, dtype_loc, &G)) return kNotTuned;
   if (!all_aligned16({value, grad_out, grad_value, workspace})) return kNotTuned;
 #define MSDA_ARGS                                                                               \
   grad_out, value, shapes, lsi, loc, attn, grad_value, grad_loc, grad_attn, workspace, N, S, M, \
-      D, Lq, L, P, G, stream
+      D, Lq, L, P, G, allow_binned, stream
   if (dtype_val == 0) return tuned_backward_typed<float, float>(MSDA_ARGS);
   if (dtype_val == 2)
     return dtype_loc == 0 ? tuned_backward_typed<bf16_t, float>(MSDA_ARGS)

@@ -24,6 +24,8 @@ def backward_flags(value: torch.Tensor, sampling_locations: torch.Tensor) -> int
     flags = 0
     if os.environ.get("MSDA_FORCE_GENERIC") == "1":
         flags |= _lib.FLAG_GENERIC
+    if os.environ.get("MSDA_ATOMIC_SCATTER") == "1":
+        flags |= _lib.FLAG_ATOMIC_SCATTER
     det = os.environ.get("MSDA_DETERMINISTIC")
     if det == "1" or (det != "0" and torch.are_deterministic_algorithms_enabled()):
         flags |= _lib.FLAG_DETERMINISTIC
