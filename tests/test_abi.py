@@ -1,0 +1,135 @@
+"""The C-ABI library: loads on a GPU-less host, exports what include/msda.h declares, and
+rejects bad arguments before anything is launched (so these run without a GPU)."""
+
+from __future__ import annotations
+
+import ctypes
+import re
+from pathlib import Path
+
+import pytest
+
+from unipercept_amd import _lib
+
+ROOT = Path(__file__).resolve().parent.parent
+HEADER = (ROOT / "include" / "msda.h").read_text()
+
+
+def declared_functions():
+    body = re.sub(r"/\*.*?\*/", "", HEADER, flags=re.S)
+    return sorted(set(re.findall(r"\b(msda_[a-z0-9_]+)\s*\(", body)))
+
+
+def test_header_and_binding_agree():
+    assert declared_functions() == sorted(_lib.EXPORTS)
+
+
+@pytest.mark.parametrize("symbol", declared_functions())
+def test_symbol_exported(symbol):
+    lib = ctypes.CDLL(str(_lib.LIB_PATH))
+    assert hasattr(lib, symbol)
+
+
+def test_version_and_error_strings():
+    lib = _lib.load()
+    assert lib.msda_version() == _lib.ABI_VERSION
+    assert lib.msda_error_string(0) == b"success"
+    for code in range(-7, 0):
+        assert lib.msda_error_string(code).startswith(b"msda:")
+
+
+def test_enum_values_match_header():
+    enums = dict(re.findall(r"\b(MSDA_[A-Z0-9_]+)\s*=\s*(-?\d+)", HEADER))
+    assert int(enums["MSDA_F32"]) == _lib.F32 and int(enums["MSDA_F64"]) == _lib.F64
+    assert int(enums["MSDA_BF16"]) == _lib.BF16 and int(enums["MSDA_F16"]) == _lib.F16
+    assert int(enums["MSDA_FLAG_DETERMINISTIC"]) == _lib.FLAG_DETERMINISTIC
+    assert int(enums["MSDA_FLAG_GENERIC"]) == _lib.FLAG_GENERIC
+    assert int(enums["MSDA_FLAG_ATOMIC_SCATTER"]) == _lib.FLAG_ATOMIC_SCATTER
+
+
+@pytest.mark.parametrize(
+    "n,step,ok",
+    # the reference's test passes im2col_step=8 and 2 with N=1
+    # (test_nn_layers_deform_attn.py:12,34,177): step = min(N, im2col_step) must divide N
+    [(1, 8, True), (1, 2, True), (8, 8, True), (8, 4, True), (6, 4, False), (8, 64, True),
+     (3, 2, False), (4, 0, False), (4, -1, False), (0, 1, False)],
+)
+def test_im2col_step(n, step, ok):
+    rc = _lib.load().msda_check_im2col_step(n, step)
+    assert (rc == 0) == ok
+    if not ok:
+        assert rc == -6
+
+
+FAKE = 0x1000  # never dereferenced: every call below fails validation first
+
+
+def _fwd(value=FAKE, shapes=FAKE, lsi=FAKE, loc=FAKE, attn=FAKE, out=FAKE,
+         dims=(1, 4, 1, 4, 2, 1, 1), dv=0, dl=0, flags=0):
+    return _lib.load().msda_forward(value, shapes, lsi, loc, attn, out, *dims, dv, dl, flags, None)
+
+
+def test_forward_argument_errors():
+    assert _fwd(value=None) == -1
+    assert _fwd(out=None) == -1
+    assert _fwd(dims=(0, 4, 1, 4, 2, 1, 1)) == -2
+    assert _fwd(dims=(1, 4, 1, 4, 2, 1, -3)) == -2
+    assert _fwd(dims=(1, 4, 1, 4, 2, 17, 1)) == -7
+    assert _fwd(dims=(1, 4, 1, 4, 2, 8, 32)) == -7
+    assert _fwd(dv=9) == -3
+    assert _fwd(dv=0, dl=2) == -3  # fp32 value with bf16 locations is not a supported pair
+    assert _fwd(dv=1, dl=0) == -3
+    assert _fwd(value=FAKE + 2) == -4  # fp32 pointer not 4-byte aligned
+    assert _fwd(shapes=FAKE + 4) == -4
+    assert _fwd(dims=(70000, 4, 1, 4, 70000, 1, 1)) == -2  # N*Lq*M over 2^31-1
+
+
+def _bwd(workspace=None, wbytes=0, dims=(2, 64, 2, 32, 64, 1, 2), dv=2, dl=2, flags=0, **kw):
+    p = dict(grad_out=FAKE, value=FAKE, shapes=FAKE, lsi=FAKE, loc=FAKE, attn=FAKE,
+             grad_value=FAKE, grad_loc=FAKE, grad_attn=FAKE)
+    p.update(kw)
+    return _lib.load().msda_backward(
+        p["grad_out"], p["value"], p["shapes"], p["lsi"], p["loc"], p["attn"], p["grad_value"],
+        p["grad_loc"], p["grad_attn"], workspace, wbytes, *dims, dv, dl, flags, None,
+    )
+
+
+def test_backward_argument_errors():
+    assert _bwd(grad_attn=None) == -1
+    assert _bwd(dims=(2, 64, 2, 32, 64, 0, 2)) == -2
+    assert _bwd(dv=5) == -3
+    need = _lib.load().msda_backward_workspace_bytes(2, 64, 2, 32, 64, 1, 2, 2, 2, 0)
+    assert need > 0
+    assert _bwd(workspace=None, wbytes=0) == -5
+    assert _bwd(workspace=FAKE * 16, wbytes=need - 1) == -5
+    assert _bwd(workspace=FAKE * 16 + 16, wbytes=need) == -5  # not 256-byte aligned
+
+
+def test_workspace_bytes():
+    ws = _lib.load().msda_backward_workspace_bytes
+    # generic fp32 / fp64 paths accumulate straight into grad_value
+    assert ws(1, 640, 2, 30, 2, 2, 2, _lib.F32, _lib.F32, 0) == 0
+    assert ws(1, 640, 2, 30, 2, 2, 2, _lib.F64, _lib.F64, 0) == 0
+    # generic 16-bit path: fp32 image of grad_value
+    assert ws(1, 640, 2, 30, 2, 2, 2, _lib.BF16, _lib.BF16, 0) == 640 * 2 * 30 * 4
+    # deterministic mode needs none
+    assert ws(1, 640, 2, 32, 2, 2, 2, _lib.BF16, _lib.BF16, _lib.FLAG_DETERMINISTIC) == 0
+    # binned path (Cityscapes shapes, batch 8): directory + 64 B per sampled point
+    n, s, m, d, l, p = 8, 43008, 8, 32, 3, 4
+    tiles = -(-s // 256)
+    qblocks = -(-s // 256)
+    dir_bytes = n * m * qblocks * tiles * 8
+    rec_bytes = n * m * qblocks * 256 * l * p * 4 * 16
+    assert ws(n, s, m, d, s, l, p, _lib.F32, _lib.F32, 0) == ((dir_bytes + 255) // 256) * 256 + rec_bytes
+    # atomic scatter on request: nothing for fp32, the fp32 image for bf16
+    assert ws(n, s, m, d, s, l, p, _lib.F32, _lib.F32, _lib.FLAG_ATOMIC_SCATTER) == 0
+    assert ws(n, s, m, d, s, l, p, _lib.BF16, _lib.F32, _lib.FLAG_ATOMIC_SCATTER) == n * s * m * d * 4
+    # invalid arguments give 0
+    assert ws(0, s, m, d, s, l, p, _lib.F32, _lib.F32, 0) == 0
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", tmp_path / "libmsda.so")
+    with pytest.raises(_lib.MsdaLibraryError):
+        _lib.load()

@@ -1,0 +1,98 @@
+"""The data-parallel path on CPU: two gloo ranks, batch sharded, one flat gradient bucket.
+
+The ranks run the MSDeformAttn layer with the CPU oracle injected as the sampling op (the HIP op
+needs a GPU); what is under test is the harness: sharding, the bucket, and that the averaged
+gradients equal those of the whole batch in one process.
+"""
+
+from __future__ import annotations
+
+import os
+import socket
+import sys
+from pathlib import Path
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = Path(__file__).resolve().parent.parent
+
+LEVELS = [(6, 8), (3, 4)]
+GLOBAL_BATCH = 4
+
+
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _make_layer():
+    from oracle import grid_sample_ref
+    from unipercept_amd.deform_attn import MSDeformAttn
+
+    torch.manual_seed(42)
+    layer = MSDeformAttn(d_model=32, n_levels=2, n_heads=4, n_points=2).double()
+    torch.nn.init.normal_(layer.sampling_offsets.weight, std=0.05)
+    torch.nn.init.normal_(layer.attention_weights.weight, std=0.05)
+    layer.op = lambda v, sh, li, lo, a, step: grid_sample_ref.deform_attn(v, sh, lo, a)
+    return layer
+
+
+def _data():
+    g = torch.Generator().manual_seed(7)
+    s = sum(h * w for h, w in LEVELS)
+    feats = torch.randn(GLOBAL_BATCH, s, 32, generator=g, dtype=torch.float64)
+    ref = torch.rand(GLOBAL_BATCH, s, len(LEVELS), 2, generator=g, dtype=torch.float64)
+    target = torch.randn(GLOBAL_BATCH, s, 32, generator=g, dtype=torch.float64)
+    return feats, ref, target
+
+
+def _loss(layer, feats, ref, target):
+    shapes = torch.tensor(LEVELS)
+    lsi = torch.cat((shapes.new_zeros(1), shapes.prod(1).cumsum(0)[:-1]))
+    out = layer(feats, ref, feats, shapes, lsi)
+    return ((out - target) ** 2).mean()
+
+
+def _worker(rank: int, world: int, port: int, out_dir: str) -> None:
+    for p in (str(ROOT), str(ROOT / "shim")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from unipercept_amd import harness
+
+        layer = _make_layer()
+        bucket = harness.FlatGradBucket.for_parameters(layer.parameters())
+        feats, ref, target = _data()
+        mine = list(harness.shard_batch(GLOBAL_BATCH, world, rank))
+        loss = _loss(layer, feats[mine], ref[mine], target[mine])
+        loss.backward()
+        # grads were accumulated into the bucket's views (p.grad aliases the bucket)
+        for p, v in zip(layer.parameters(), bucket.views):
+            assert p.grad.data_ptr() == v.data_ptr()
+        work = bucket.all_reduce(async_op=True)
+        work.wait()
+        torch.save(bucket.flat.clone(), os.path.join(out_dir, f"rank{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_two_rank_gradient_average_equals_full_batch(tmp_path):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    got = [torch.load(tmp_path / f"rank{r}.pt", weights_only=True) for r in range(world)]
+    assert torch.equal(got[0], got[1])
+
+    layer = _make_layer()
+    feats, ref, target = _data()
+    loss = _loss(layer, feats, ref, target)  # mean over the whole batch
+    loss.backward()
+    want = torch.cat([p.grad.reshape(-1) for p in layer.parameters()])
+    assert torch.allclose(got[0].double(), want, rtol=1e-5, atol=1e-8)

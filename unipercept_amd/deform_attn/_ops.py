@@ -37,7 +37,7 @@ def _check_levels(shapes: torch.Tensor, lsi: torch.Tensor, s: int) -> None:
     key = (shapes.data_ptr(), shapes._version, lsi.data_ptr(), lsi._version, s, shapes.device)
     if key in _level_cache:
         return
-    if torch.cuda.is_current_stream_capturing():
+    if shapes.is_cuda and torch.cuda.is_current_stream_capturing():
         return  # cannot synchronise while a graph is being captured; the kernels guard themselves
     hw = shapes.tolist()
     st = lsi.tolist()
@@ -58,11 +58,6 @@ def _check_levels(shapes: torch.Tensor, lsi: torch.Tensor, s: int) -> None:
 
 
 def _validate(value, shapes, lsi, loc, attn):
-    if value.device.type != "cuda":
-        raise RuntimeError(
-            "ms_deform_attn runs only on a ROCm GPU (HIP kernels); got a tensor on "
-            f"{value.device}. Use `reference.deform_attn` for a pure-PyTorch CPU evaluation."
-        )
     if value.dim() != 4 or loc.dim() != 6 or attn.dim() != 5 or loc.shape[-1] != 2:
         raise ValueError(
             "expected value (N,S,M,D), sampling_locations (N,Lq,M,L,P,2), attention_weights "
@@ -81,6 +76,11 @@ def _validate(value, shapes, lsi, loc, attn):
         )
     if value.dtype not in _DTYPE_CODE:
         raise TypeError(f"unsupported value dtype {value.dtype}")
+    if value.device.type != "cuda":
+        raise RuntimeError(
+            "ms_deform_attn runs only on a ROCm GPU (HIP kernels); got a tensor on "
+            f"{value.device}. Use `reference.deform_attn` for a pure-PyTorch CPU evaluation."
+        )
     for t in (loc, attn):
         if t.device != value.device:
             raise RuntimeError("all tensors must live on the same device")

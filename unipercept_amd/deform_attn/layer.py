@@ -38,6 +38,8 @@ class MSDeformAttn(nn.Module):
         self.attention_weights = nn.Linear(d_model, n_heads * n_levels * n_points)
         self.value_proj = nn.Linear(d_model, d_model)
         self.output_proj = nn.Linear(d_model, d_model)
+        # the sampling op, with the reference Function's positional signature
+        self.op = MultiScaleDeformAttnFunction.apply
         self.reset_parameters()
 
     def reset_parameters(self) -> None:
@@ -107,7 +109,7 @@ class MSDeformAttn(nn.Module):
         value, locations, weights = self.sampling_inputs(
             query, reference_points, input_flatten, input_spatial_shapes, input_padding_mask
         )
-        out = MultiScaleDeformAttnFunction.apply(
+        out = self.op(
             value, input_spatial_shapes, input_level_start_index, locations, weights,
             self.im2col_step,
         )

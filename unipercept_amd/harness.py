@@ -199,7 +199,7 @@ def layer_param_count(d_model: int, heads: int, levels: int, points: int) -> int
 
 
 class FlatGradBucket:
-    """One flat fp32 bucket for the layer's parameter gradients, all-reduced (sum, then divided
+    """One flat bucket (fp32 unless built from parameters of another dtype) for the layer's parameter gradients, all-reduced (sum, then divided
     by the world size: DDP semantics) in a single collective.  The tensors handed in become views
     into the bucket, so no copy happens per step."""
 
@@ -215,7 +215,7 @@ class FlatGradBucket:
     @classmethod
     def for_parameters(cls, params) -> "FlatGradBucket":
         params = [p for p in params if p.requires_grad]
-        bucket = cls([p.numel() for p in params], params[0].device, torch.float32)
+        bucket = cls([p.numel() for p in params], params[0].device, params[0].dtype)
         for p, v in zip(params, bucket.views):
             p.grad = v.view_as(p)
         return bucket
