@@ -6,8 +6,10 @@ module body is absent from the reference snapshot).  The arithmetic lives in
 ``torch.nn.functional.grid_sample`` (bilinear, zero padding, ``align_corners=False``), a
 third-party dependency of the reference (torch >= 2.5.1, pyproject.toml:26).
 
-Pinned by ``tests/test_oracle.py`` against the golden vectors in ``tests/golden/`` that were
-produced in the build container by ``tests/golden/make_golden.py``.
+PARITY UNPINNED against the reference's own outputs (it holds no golden vectors for this path and
+its implementation is absent).  Pinned instead by ``tests/test_oracle.py`` against the vectors in
+``tests/golden/`` that ``tests/golden/make_golden.py`` produced in the build container from the
+canonical formulation.
 """
 
 from __future__ import annotations

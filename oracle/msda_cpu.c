@@ -7,8 +7,13 @@
  * per-level `F.grid_sample(mode="bilinear", padding_mode="zeros", align_corners=False)` followed
  * by an attention-weighted sum; the arithmetic itself lives in PyTorch (aten::grid_sampler_2d and
  * its backward), which is a third-party dependency of the reference (torch >= 2.5.1,
- * pyproject.toml:26 of the reference).  The same formulation is what the golden vectors under
- * tests/golden/ were generated from; this file is pinned against them by tests/test_oracle.py.
+ * pyproject.toml:26 of the reference).
+ *
+ * PARITY UNPINNED against the reference's own outputs: the reference holds no golden vectors for
+ * this path and its implementation is absent from the snapshot.  The pin used instead is the set
+ * of vectors under tests/golden/, generated in the build container from the canonical
+ * grid_sample formulation (tests/golden/make_golden.py); tests/test_oracle.py checks this file
+ * against them.
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
  * The product path (unipercept_amd) never does.
