@@ -20,6 +20,7 @@
 // per workgroup, accumulates the tile in LDS (no float atomics there either) and stores it once.
 #pragma once
 
+#include <cstdlib>
 #include <initializer_list>
 #include <type_traits>
 
@@ -187,7 +188,7 @@ __device__ __forceinline__ void stage_chunk(const LevelInfo* lv, const LT* __res
       dst[2] = frec;
     }
     if constexpr (EMIT) {
-      if (f.any && a != 0.f) {
+      if (f.any && a != 0.f && emit.records != nullptr) {
         uint32_t tiles[4] = {0, 0, 0, 0};
         const int n = footprint_tiles(f, L_.start, emit.ts_shift, tiles);
         uint4 rec;
@@ -309,12 +310,16 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t* data, int n, 
   return total;
 }
 
+// positions per destination tile, by head dim
+__host__ __device__ constexpr int tile_positions(int D) { return D <= 32 ? 256 : 128; }
+
 struct BinPlan {
   int ts_shift;     // log2 of the tile size in positions
   int n_tiles;      // ceil(S / TS)
   int qb;           // queries per query-side workgroup
   int n_qblocks;    // ceil(Lq / qb)
   uint32_t region;  // records per workgroup region
+  int ablate;       // diagnostic runs only: bit mask of phases to skip (results are then wrong)
 };
 
 // MODE 0: grad_loc / grad_attn + grad_value by global fp32 atomics into `gv_acc`
@@ -350,7 +355,7 @@ __global__ __launch_bounds__(256) void bwd_query_kernel(
   uint32_t* tile_off = tile_cnt + plan.n_tiles;
   EmitCtx emit{};
 
-  if constexpr (MODE == 1) {
+  if (MODE == 1 && !(plan.ablate & 1)) {
     // ---- count the records of this workgroup per destination tile ----
     for (int t = threadIdx.x; t < plan.n_tiles; t += 256) tile_cnt[t] = 0;
     __syncthreads();
@@ -407,53 +412,75 @@ __global__ __launch_bounds__(256) void bwd_query_kernel(
     float go[CPL];
     Chunk<VT>::load(reinterpret_cast<const char*>(grad_out) + (triple * D + lane * CPL) * sizeof(VT), go);
 
-    for (int i = 0; i < LP; ++i) {
-      const uint4 wr = r[3 * i], orr = r[3 * i + 1], fr = r[3 * i + 2];
-      const uint32_t oraw[4] = {orr.x, orr.y, orr.z, orr.w};
-      const float lx = __uint_as_float(fr.x), ly = __uint_as_float(fr.y);
-      const float aW = __uint_as_float(fr.z), aH = __uint_as_float(fr.w);
-      const float hx = 1.f - lx, hy = 1.f - ly;
-      float v[4][CPL];
-      uint32_t o[4];
+    // G points per pass: after the pass lane j of the group keeps the results of point i0 + j, so
+    // the group writes G consecutive grad_attn / grad_loc elements with one store each
+    for (int i0 = 0; i0 < LP; i0 += G) {
+      float keep_sv = 0.f, keep_sx = 0.f, keep_sy = 0.f;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        o[k] = (oraw[k] & ~15u) + lane_b;
-        Chunk<VT>::load(vb + o[k], v[k]);
-      }
-      float dot[4];
+      for (int k = 0; k < G; ++k) {
+        const int i = min(i0 + k, LP - 1);  // a pass past the end redoes the last point (unused)
+        const uint4 wr = r[3 * i], orr = r[3 * i + 1], fr = r[3 * i + 2];
+        const uint32_t oraw[4] = {orr.x, orr.y, orr.z, orr.w};
+        const float lx = __uint_as_float(fr.x), ly = __uint_as_float(fr.y);
+        const float aW = __uint_as_float(fr.z), aH = __uint_as_float(fr.w);
+        const float hx = 1.f - lx, hy = 1.f - ly;
+        float v[4][CPL];
+        uint32_t o[4];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        float d = 0.f;
+        for (int c4 = 0; c4 < 4; ++c4) {
+          o[c4] = (oraw[c4] & ~15u) + lane_b;
+          if (plan.ablate & 4) {
 #pragma unroll
-        for (int c = 0; c < CPL; ++c) d = fmaf(go[c], v[k][c], d);
-        dot[k] = (oraw[k] & 1u) ? d : 0.f;  // a corner outside the level contributes nothing
-      }
-      if constexpr (MODE == 0) {
-        const float aw[4] = {__uint_as_float(wr.x), __uint_as_float(wr.y), __uint_as_float(wr.z),
-                             __uint_as_float(wr.w)};
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          if (live && aw[k] != 0.f) {
-            float* dst = gv_acc + slab_elems + o[k] / sizeof(VT);
-#pragma unroll
-            for (int c = 0; c < CPL; ++c) atomicAdd(dst + c, aw[k] * go[c]);
+            for (int c = 0; c < CPL; ++c) v[c4][c] = __uint_as_float(o[c4] + c);
+          } else {
+            Chunk<VT>::load(vb + o[c4], v[c4]);
           }
         }
-      } else {
-        (void)wr;
+        float dot[4];
+#pragma unroll
+        for (int c4 = 0; c4 < 4; ++c4) {
+          float d = 0.f;
+#pragma unroll
+          for (int c = 0; c < CPL; ++c) d = fmaf(go[c], v[c4][c], d);
+          dot[c4] = (oraw[c4] & 1u) ? d : 0.f;  // a corner outside the level contributes nothing
+        }
+        if constexpr (MODE == 0) {
+          const float aw[4] = {__uint_as_float(wr.x), __uint_as_float(wr.y),
+                               __uint_as_float(wr.z), __uint_as_float(wr.w)};
+#pragma unroll
+          for (int c4 = 0; c4 < 4; ++c4) {
+            if (live && aw[c4] != 0.f && i0 + k < LP) {
+              float* dst = gv_acc + slab_elems + o[c4] / sizeof(VT);
+#pragma unroll
+              for (int c = 0; c < CPL; ++c) atomicAdd(dst + c, aw[c4] * go[c]);
+            }
+          }
+        } else {
+          (void)wr;
+        }
+        // w = {hy*hx, hy*lx, ly*hx, ly*lx}; dw/dx = {-hy, hy, -ly, ly}; dw/dy = {-hx, -lx, hx, lx}
+        float sv = hy * fmaf(hx, dot[0], lx * dot[1]) + ly * fmaf(hx, dot[2], lx * dot[3]);
+        float sx = fmaf(hy, dot[1] - dot[0], ly * (dot[3] - dot[2]));
+        float sy = fmaf(hx, dot[2] - dot[0], lx * (dot[3] - dot[1]));
+        sv = group_sum<G>(sv);
+        sx = group_sum<G>(sx);
+        sy = group_sum<G>(sy);
+        if (lane == k) {
+          keep_sv = sv;
+          keep_sx = aW * sx;
+          keep_sy = aH * sy;
+        }
       }
-      // w = {hy*hx, hy*lx, ly*hx, ly*lx}; dw/dx = {-hy, hy, -ly, ly}; dw/dy = {-hx, -lx, hx, lx}
-      float sv = hy * fmaf(hx, dot[0], lx * dot[1]) + ly * fmaf(hx, dot[2], lx * dot[3]);
-      float sx = fmaf(hy, dot[1] - dot[0], ly * (dot[3] - dot[2]));
-      float sy = fmaf(hx, dot[2] - dot[0], lx * (dot[3] - dot[1]));
-      sv = group_sum<G>(sv);
-      sx = group_sum<G>(sx);
-      sy = group_sum<G>(sy);
-      if (lane == 0 && live) {
+      const int i = i0 + lane;
+      if (i < LP && live && !(plan.ablate & 2)) {
         const int64_t gi = triple * LP + i;
-        Elem<LT>::store(grad_attn + gi, sv);
-        Elem<LT>::store(grad_loc + 2 * gi, aW * sx);
-        Elem<LT>::store(grad_loc + 2 * gi + 1, aH * sy);
+        Elem<LT>::store(grad_attn + gi, keep_sv);
+        if constexpr (sizeof(LT) == 4) {
+          *reinterpret_cast<float2*>(grad_loc + 2 * gi) = make_float2(keep_sx, keep_sy);
+        } else {
+          Elem<LT>::store(grad_loc + 2 * gi, keep_sx);
+          Elem<LT>::store(grad_loc + 2 * gi + 1, keep_sy);
+        }
       }
     }
     __syncthreads();
@@ -464,11 +491,30 @@ __global__ __launch_bounds__(256) void bwd_query_kernel(
 // Backward, destination side: one workgroup per (batch, head, tile of TS positions)
 //
 // ds_add_f32 runs at ~0.3 lanes/clk/CU on gfx950 (measured; ds_add_u32 does ~12), so the tile is
-// NOT accumulated with LDS float atomics.  Instead each slice of 256 records is bucketed by
-// destination position with integer LDS atomics (count, scan, fill), the slice's grad_out rows
-// are staged in LDS once, and every group of G lanes then owns TS/(256/G) consecutive positions
-// and adds its bucket entries into the LDS tile with plain read-modify-write.
+// NOT accumulated with LDS float atomics.  Each slice of 256 records (one per thread) is
+// bucketed by destination position with integer LDS atomics (count, DPP scan, fill); the
+// slice's grad_out rows go global -> LDS by LDS-DMA, once per record; then every group of D/8
+// lanes, which owns PPG consecutive positions for the whole life of the workgroup, walks the
+// bucket of each of its positions and accumulates in registers.  The tile is stored from those
+// registers at the end: no accumulator in LDS, no float atomic anywhere.
 // ---------------------------------------------------------------------------------------------
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_u32(uint32_t v) {
+  return static_cast<uint32_t>(
+      __builtin_amdgcn_update_dpp(0, static_cast<int>(v), CTRL, ROW_MASK, 0xF, true));
+}
+
+// inclusive prefix sum over the 64 lanes of a wave, on the DPP path
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t x) {
+  x += dpp_u32<0x111, 0xF>(x);  // row_shr:1
+  x += dpp_u32<0x112, 0xF>(x);  // row_shr:2
+  x += dpp_u32<0x114, 0xF>(x);  // row_shr:4
+  x += dpp_u32<0x118, 0xF>(x);  // row_shr:8
+  x += dpp_u32<0x142, 0xA>(x);  // row_bcast15 into rows 1 and 3
+  x += dpp_u32<0x143, 0xC>(x);  // row_bcast31 into rows 2 and 3
+  return x;
+}
+
 template <typename VT, int G>
 __global__ __launch_bounds__(256) void bwd_tile_kernel(
     const VT* __restrict__ grad_out, const int64_t* __restrict__ shapes,
@@ -477,74 +523,95 @@ __global__ __launch_bounds__(256) void bwd_tile_kernel(
     BinPlan plan) {
   constexpr int CPL = Chunk<VT>::kCPL;
   constexpr int D = G * CPL;
-  constexpr int GPB = 256 / G;   // groups per workgroup
-  constexpr int R = 256;         // records per slice (one per thread)
-  constexpr int SPG = R / GPB;   // record slots staged per group (= G)
+  constexpr int R = 256;                      // records per slice (one per thread)
+  constexpr int ROWB = D * sizeof(VT);        // bytes of one grad_out row of one head
+  constexpr int RPI = 64 / G;                 // rows one wave-wide LDS-DMA instruction moves
+  constexpr int PL = D / 8;                   // lanes per bucket entry, 8 channels each
+  constexpr int PG = 256 / PL;                // entry groups per workgroup
+  constexpr int CPR = (8 * sizeof(VT)) / 16;  // 16-byte chunks a lane reads per row (2 or 1)
+  constexpr int TS = tile_positions(D);       // positions per tile
+  constexpr int PPG = TS / PG;                // positions owned by one entry group
   extern __shared__ uint4 lds[];
   __shared__ LevelInfo lv[kMaxLevelsTuned];
-  __shared__ uint32_t scan_tmp[256];
   __shared__ uint32_t wsum[4];
+  __shared__ uint32_t n_runs_s, total_s;
 
-  const int TS = 1 << plan.ts_shift;
-  const int PPG = TS / GPB;  // positions owned by one group
-  float* acc = reinterpret_cast<float*>(lds);                     // TS * D floats
-  float* gstage = acc + TS * D;                                   // R * D floats
-  uint2* entries = reinterpret_cast<uint2*>(gstage + R * D);      // 4 * R entries
-  uint32_t* cnt = reinterpret_cast<uint32_t*>(entries + 4 * R);   // TS
-  uint32_t* start = cnt + TS;                                     // TS + 1
-  uint32_t* cursor = start + TS + 1;                              // TS
-  uint32_t* pre = cursor + TS;                                    // n_qblocks + 1
-  uint32_t* offs = pre + plan.n_qblocks + 1;                      // n_qblocks
+  char* gstage = reinterpret_cast<char*>(lds);                                // R rows
+  uint2* entries = reinterpret_cast<uint2*>(gstage + R * ROWB);               // 4 * R
+  uint32_t* cnt = reinterpret_cast<uint32_t*>(entries + 4 * R);               // TS
+  uint32_t* start = cnt + TS;                                                 // TS + 1
+  uint32_t* cursor = start + TS + 1;                                          // TS
+  uint32_t* run_cnt = cursor + TS;                                            // n_qblocks
+  uint32_t* run_base = run_cnt + plan.n_qblocks;                              // n_qblocks
 
   const int b = blockIdx.y;
   const int m = blockIdx.x % M;
   const int tile = plan.n_tiles - 1 - blockIdx.x / M;  // coarse (record-heavy) levels first
   const int64_t slab = static_cast<int64_t>(b) * M + m;
   if (threadIdx.x < L) lv[threadIdx.x] = load_level(shapes, lsi, threadIdx.x, S);
-  for (int i = threadIdx.x; i < TS * D; i += 256) acc[i] = 0.f;
+  if (threadIdx.x == 0) {
+    n_runs_s = 0;
+    total_s = 0;
+  }
   for (int i = threadIdx.x; i < TS; i += 256) cnt[i] = 0;
+  __syncthreads();
+  // the non-empty runs of this tile: (record count, first record index inside the slab)
   for (int qbk = threadIdx.x; qbk < plan.n_qblocks; qbk += 256) {
     const uint2 e = dir[(slab * plan.n_qblocks + qbk) * plan.n_tiles + tile];
-    offs[qbk] = e.x;
-    pre[qbk] = e.y;
+    if (e.y != 0) {
+      const uint32_t at = atomicAdd(&n_runs_s, 1u);
+      run_cnt[at] = e.y;
+      run_base[at] = static_cast<uint32_t>(qbk) * plan.region + e.x;
+      atomicAdd(&total_s, e.y);
+    }
   }
-  if (threadIdx.x == 0) pre[plan.n_qblocks] = 0;
   __syncthreads();
-  const uint32_t total = block_exclusive_scan(pre, plan.n_qblocks + 1, scan_tmp);
+  const int n_runs = static_cast<int>(n_runs_s);
+  const uint32_t total = total_s;
 
-  const int g = threadIdx.x / G, lane = threadIdx.x % G;
   const int wave = threadIdx.x >> 6, wlane = threadIdx.x & 63;
   const uint4* slab_records = records + slab * plan.n_qblocks * static_cast<int64_t>(plan.region);
-  const char* go_base = reinterpret_cast<const char*>(grad_out);
+  const char* go_slab = reinterpret_cast<const char*>(grad_out) +
+                        (static_cast<int64_t>(b) * Lq * M + m) * ROWB;  // + q * M * ROWB
   const uint32_t tile_u = static_cast<uint32_t>(tile);
 
+  // this thread's position in the run list: record `threadIdx.x + k * R` of the flattened order
+  int run = 0;
+  uint32_t off = threadIdx.x;
+  while (run < n_runs && off >= run_cnt[run]) off -= run_cnt[run++];
+  uint4 rec = make_uint4(kRecInvalid, 0, 0, 0);
+  if (run < n_runs) rec = slab_records[run_base[run] + off];
+
+  const int pg = threadIdx.x / PL, pl = threadIdx.x % PL;
+  float sum[PPG][8];
+#pragma unroll
+  for (int p = 0; p < PPG; ++p)
+#pragma unroll
+    for (int c = 0; c < 8; ++c) sum[p][c] = 0.f;
+
   for (uint32_t base = 0; base < total; base += R) {
-    // ---- A: one record per thread ----
-    const uint32_t r = base + threadIdx.x;
-    uint4 rec = make_uint4(kRecInvalid, 0, 0, 0);
-    if (r < total) {
-      int lo = 0, hi = plan.n_qblocks;  // largest qbk with pre[qbk] <= r
-      while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if (pre[mid] <= r) lo = mid; else hi = mid;
-      }
-      rec = slab_records[static_cast<int64_t>(lo) * plan.region + offs[lo] + (r - pre[lo])];
-    }
-    const bool have = rec.x != kRecInvalid;
-    // ---- B: grad_out rows of this group's record slots, straight into registers ----
-    float go[SPG][CPL];
+    // ---- A: prefetch the next slice's record ----
+    off += R;
+    while (run < n_runs && off >= run_cnt[run]) off -= run_cnt[run++];
+    uint4 rec_next = make_uint4(kRecInvalid, 0, 0, 0);
+    if (run < n_runs) rec_next = slab_records[run_base[run] + off];
+
+    // ---- B: grad_out rows of this wave's 64 record slots, global -> LDS ----
 #pragma unroll
-    for (int k = 0; k < SPG; ++k) {
-      const uint32_t qk = __shfl(rec.x, k, G);  // record slot g*SPG + k lives in lane k of the group
-      if (qk != kRecInvalid) {
-        const int64_t triple = (static_cast<int64_t>(b) * Lq + (qk & 0x0fffffffu)) * M + m;
-        Chunk<VT>::load(go_base + (triple * D + lane * CPL) * sizeof(VT), go[k]);
-      } else {
-#pragma unroll
-        for (int c = 0; c < CPL; ++c) go[k][c] = 0.f;
-      }
+    for (int k = 0; k < G; ++k) {
+      const int src = k * RPI + wlane / G;  // lane of the wave that holds the row's record
+      const uint32_t qk = __shfl(rec.x, src, 64);
+      // an empty slot reads row 0 (a valid address); nothing refers to it afterwards
+      const uint32_t q = (qk == kRecInvalid || (plan.ablate & 16)) ? 0u : (qk & 0x0fffffffu);
+      const char* srcp = go_slab + static_cast<int64_t>(q) * M * ROWB + (wlane % G) * 16;
+      char* dstp = gstage + (wave * 64 + k * RPI) * ROWB;  // wave-uniform; lanes land 16 B apart
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)srcp,
+          (__attribute__((address_space(3))) void*)dstp, 16, 0, 0);
     }
+
     // ---- C: footprint of the thread's own record, count its in-tile corners per position ----
+    const bool have = rec.x != kRecInvalid;
     uint32_t loc_pix[4];
     float loc_w[4];
     bool in_tile[4] = {false, false, false, false};
@@ -566,76 +633,72 @@ __global__ __launch_bounds__(256) void bwd_tile_kernel(
     // ---- D: exclusive scan of the per-position counts (TS <= 256: one per thread) ----
     {
       const uint32_t c = threadIdx.x < static_cast<unsigned>(TS) ? cnt[threadIdx.x] : 0u;
-      uint32_t x = c;
-#pragma unroll
-      for (int sft = 1; sft < 64; sft <<= 1) {
-        const uint32_t y = __shfl_up(x, sft, 64);
-        if (wlane >= sft) x += y;
-      }
+      const uint32_t x = wave_inclusive_scan(c);
       if (wlane == 63) wsum[wave] = x;
       __syncthreads();
-      uint32_t off = 0;
+      uint32_t pre = 0;
 #pragma unroll
-      for (int w = 0; w < 4; ++w) off += (w < wave) ? wsum[w] : 0u;
+      for (int w = 0; w < 4; ++w) pre += (w < wave) ? wsum[w] : 0u;
       if (threadIdx.x < static_cast<unsigned>(TS)) {
-        start[threadIdx.x] = off + x - c;
-        cursor[threadIdx.x] = off + x - c;
+        start[threadIdx.x] = pre + x - c;
+        cursor[threadIdx.x] = pre + x - c;
         cnt[threadIdx.x] = 0;  // ready for the next slice
       }
-      if (threadIdx.x == 255) start[TS] = off + x;
+      if (threadIdx.x == 255) start[TS] = pre + x;
     }
     __syncthreads();
-    // ---- E: fill the buckets; stage the grad_out rows ----
+    // ---- E: fill the buckets ----
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       if (in_tile[k]) {
-        const uint32_t pos = atomicAdd(&cursor[loc_pix[k]], 1u);
-        entries[pos] = make_uint2(threadIdx.x | (loc_pix[k] << 16), __float_as_uint(loc_w[k]));
+        const uint32_t at = atomicAdd(&cursor[loc_pix[k]], 1u);
+        entries[at] = make_uint2(threadIdx.x | (loc_pix[k] << 16), __float_as_uint(loc_w[k]));
       }
     }
-#pragma unroll
-    for (int k = 0; k < SPG; ++k) {
-      float* dst = gstage + (g * SPG + k) * D + lane * CPL;
-#pragma unroll
-      for (int c = 0; c < CPL; c += 4)
-        *reinterpret_cast<float4*>(dst + c) = make_float4(go[k][c], go[k][c + 1], go[k][c + 2], go[k][c + 3]);
-    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the LDS-DMA rows have landed
     __syncthreads();
-    // ---- F: each group adds the entries of the positions it owns ----
-    {
-      const uint32_t e0 = start[min(g * PPG, TS)], e1 = start[min((g + 1) * PPG, TS)];
-      for (uint32_t e = e0; e < e1; ++e) {
-        const uint2 ent = entries[e];
-        const float w = __uint_as_float(ent.y);
-        const float* row = gstage + (ent.x & 0xffffu) * D + lane * CPL;
-        float* dst = acc + (ent.x >> 16) * D + lane * CPL;
+    // ---- F: every entry group walks the buckets of its own positions ----
+    if (!(plan.ablate & 8)) {
 #pragma unroll
-        for (int c = 0; c < CPL; c += 4) {
-          const float4 rv = *reinterpret_cast<const float4*>(row + c);
-          float4 av = *reinterpret_cast<float4*>(dst + c);
-          av.x = fmaf(w, rv.x, av.x);
-          av.y = fmaf(w, rv.y, av.y);
-          av.z = fmaf(w, rv.z, av.z);
-          av.w = fmaf(w, rv.w, av.w);
-          *reinterpret_cast<float4*>(dst + c) = av;
+      for (int p = 0; p < PPG; ++p) {
+        const uint32_t e0 = start[pg * PPG + p], e1 = start[pg * PPG + p + 1];
+        for (uint32_t e = e0; e < e1; ++e) {
+          const uint2 ent = entries[e];
+          const float w = __uint_as_float(ent.y);
+          const char* row = gstage + (ent.x & 0xffffu) * ROWB;
+          float rv[8];
+          if constexpr (CPR == 2) {  // fp32: chunks pl and pl + PL of the row
+            const float4 t0 = *reinterpret_cast<const float4*>(row + pl * 16);
+            const float4 t1 = *reinterpret_cast<const float4*>(row + (pl + PL) * 16);
+            rv[0] = t0.x; rv[1] = t0.y; rv[2] = t0.z; rv[3] = t0.w;
+            rv[4] = t1.x; rv[5] = t1.y; rv[6] = t1.z; rv[7] = t1.w;
+          } else {  // 16-bit: chunk pl holds this lane's 8 channels
+            Chunk<VT>::load(row + pl * 16, rv);
+          }
+#pragma unroll
+          for (int c = 0; c < 8; ++c) sum[p][c] = fmaf(w, rv[c], sum[p][c]);
         }
       }
     }
     __syncthreads();
+    rec = rec_next;
   }
 
-  // store the tile: one group per position
+  // store the tile from the registers: lane pl of an entry group holds channels
+  // [pl*4, pl*4+4) and [(pl+PL)*4, ...) of its positions (fp32), or [pl*8, pl*8+8) (16-bit)
   const int64_t row_elems = static_cast<int64_t>(M) * D;
-  for (int local = g; local < TS; local += GPB) {
-    const int64_t pos = static_cast<int64_t>(tile) * TS + local;
-    if (pos >= S) break;
-    float v[CPL];
 #pragma unroll
-    for (int c = 0; c < CPL; ++c) v[c] = acc[local * D + lane * CPL + c];
-    Chunk<VT>::store(reinterpret_cast<char*>(grad_value) +
-                         (((static_cast<int64_t>(b) * S + pos) * row_elems) + m * D + lane * CPL) *
-                             sizeof(VT),
-                     v);
+  for (int p = 0; p < PPG; ++p) {
+    const int64_t pos = static_cast<int64_t>(tile) * TS + pg * PPG + p;
+    if (pos >= S) break;
+    char* dst = reinterpret_cast<char*>(grad_value) +
+                (((static_cast<int64_t>(b) * S + pos) * row_elems) + m * D) * sizeof(VT);
+    if constexpr (CPR == 2) {
+      *reinterpret_cast<float4*>(dst + pl * 16) = make_float4(sum[p][0], sum[p][1], sum[p][2], sum[p][3]);
+      *reinterpret_cast<float4*>(dst + (pl + PL) * 16) = make_float4(sum[p][4], sum[p][5], sum[p][6], sum[p][7]);
+    } else {
+      Chunk<VT>::store(dst + pl * 16, sum[p]);
+    }
   }
 }
 
@@ -689,7 +752,7 @@ inline bool all_aligned16(std::initializer_list<const void*> ps) {
 inline bool make_bin_plan(int N, int S, int M, int D, int Lq, int L, int P, BinPlan* plan,
                           size_t* dir_bytes, size_t* rec_bytes) {
   if (D > 64) return false;                  // the LDS row stage of a slice is 256 * D * 4 B
-  const int ts_shift = D <= 32 ? 8 : 7;      // TS * D * 4 B = 32 KB of LDS
+  const int ts_shift = tile_positions(D) == 256 ? 8 : 7;
   const int TS = 1 << ts_shift;
   const int64_t n_tiles = (static_cast<int64_t>(S) + TS - 1) / TS;
   const int qb = 256;
@@ -707,6 +770,7 @@ inline bool make_bin_plan(int N, int S, int M, int D, int Lq, int L, int P, BinP
   plan->qb = qb;
   plan->n_qblocks = static_cast<int>(n_qblocks);
   plan->region = static_cast<uint32_t>(region);
+  plan->ablate = getenv("MSDA_EXP_ABLATE") ? atoi(getenv("MSDA_EXP_ABLATE")) : 0;
   *dir_bytes = (static_cast<size_t>(dir_b) + 255) & ~static_cast<size_t>(255);
   *rec_bytes = static_cast<size_t>(rec_b);
   return true;
@@ -782,8 +846,8 @@ int tuned_backward_typed(const void* grad_out, const void* value, const int64_t*
                         static_cast<size_t>(plan.n_tiles) * 8;
     const dim3 tgrid(static_cast<unsigned>(plan.n_tiles) * M, N);
     const size_t TSz = static_cast<size_t>(1) << plan.ts_shift;
-    const size_t tlds = TSz * D * 4 + 256 * static_cast<size_t>(D) * 4 + 4 * 256 * 8 +
-                        (3 * TSz + 1) * 4 + (2 * static_cast<size_t>(plan.n_qblocks) + 1) * 4;
+    const size_t tlds = 256 * static_cast<size_t>(D) * sizeof(VT) + 4 * 256 * 8 +
+                        (3 * TSz + 1) * 4 + 2 * static_cast<size_t>(plan.n_qblocks) * 4;
 #define MSDA_TB(GG)                                                                              \
   hipLaunchKernelGGL((bwd_query_kernel<VT, LT, GG, 1>), qgrid, dim3(256), qlds, stream,          \
                      static_cast<const VT*>(grad_out), static_cast<const VT*>(value), shapes,    \
@@ -807,6 +871,7 @@ int tuned_backward_typed(const void* grad_out, const void* value, const int64_t*
   plan.qb = 256;
   plan.n_qblocks = (Lq + plan.qb - 1) / plan.qb;
   plan.n_tiles = 0;
+  plan.ablate = 0;
   const dim3 grid(static_cast<unsigned>(plan.n_qblocks) * M, N);
   const size_t lds = static_cast<size_t>(GPB) * group_stride_slots(LP, 3) * 16;
   const int64_t total = static_cast<int64_t>(N) * S * M * D;
