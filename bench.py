@@ -172,6 +172,15 @@ def main() -> None:
             ("forward", fwd_ms, ab["fwd"]) if args.fwd_only or fwd_ms > bwd_ms else ("backward", bwd_ms, ab["bwd"])
         )
         achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
+        # HBM bytes per launch from the PMC counters are collected offline (rocprofv3 cannot run
+        # inside this process); tools/collect_profiles.sh leaves them in profiles/hbm_traffic.json
+        traffic = None
+        try:
+            rec = json.loads((ROOT / "profiles" / "hbm_traffic.json").read_text()).get(f"{w.name}:{args.dist}")
+            if rec is not None and batch == w.batch:
+                traffic = rec[dom]
+        except (OSError, ValueError, KeyError):
+            traffic = None
         step_bytes = ab["fwd"] if args.fwd_only else ab["fwd_bwd"]
         line = {
             "metric": "msdeformattn_fwd_bwd_sampled_points_per_sec"
@@ -213,7 +222,7 @@ def main() -> None:
                 "peak": HBM_PEAK / 1e9,
                 "unit": "GB/s",
                 "frac": achieved * 1e9 / HBM_PEAK,
-                "traffic": None,
+                "traffic": traffic,
                 "algorithmic_bytes_per_launch": dom_bytes,
                 "avg_launch_ms": dom_ms,
             },

@@ -1,0 +1,17 @@
+#!/bin/bash
+# Collects the rocprofv3 evidence for one bench configuration on the GPU box.
+#   usage: tools/collect_profiles.sh <tag> [bench args...]
+# Writes raw CSVs under gpurun_out/prof_<tag>/ and a summary JSON/markdown next to them;
+# copy the summaries into profiles/ afterwards.
+tag=$1; shift
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
+out=gpurun_out/prof_$tag
+mkdir -p "$out"
+args="--steps 10 --warmup 3 --no-cpu-baseline $*"
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/kt" -- python bench.py $args > "$out/bench_under_trace.json" 2> "$out/kt.err" || exit 1
+for pass in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum"; do
+  name=$(echo "$pass" | cut -d' ' -f1)
+  timeout -s KILL 120 rocprofv3 --pmc $pass --output-format csv -d "$out/pmc_$name" -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline "$@" > /dev/null 2> "$out/pmc_$name.err" || exit 1
+done
+timeout -k 10 200 python bench.py --steps 50 --warmup 10 "$@" > "$out/bench.json" 2> "$out/bench.err" || exit 1
+python tools/summarize_profiles.py "$out" "$tag"

@@ -1,0 +1,52 @@
+"""Turns the raw rocprofv3 CSVs of tools/collect_profiles.sh into a summary (markdown + json)."""
+import collections, csv, glob, json, sys
+
+out, tag = sys.argv[1], sys.argv[2]
+
+
+def kernel_stats():
+    rows = []
+    for r in csv.DictReader(open(glob.glob(f"{out}/kt/**/*_kernel_stats.csv", recursive=True)[0])):
+        if "msda" in r["Name"] or "rocclr" in r["Name"]:
+            rows.append({"kernel": r["Name"].split("(")[0], "calls": int(r["Calls"]),
+                         "avg_ms": float(r["AverageNs"]) / 1e6, "min_ms": float(r["MinNs"]) / 1e6,
+                         "max_ms": float(r["MaxNs"]) / 1e6})
+    return rows
+
+
+def counters(name):
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for path in glob.glob(f"{out}/pmc_{name}/**/*_counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(path)):
+            if "msda" in r["Kernel_Name"]:
+                agg[r["Kernel_Name"].split("(")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in agg.items()}
+
+
+stats = kernel_stats()
+pmc = {}
+for name in ("FETCH_SIZE", "WRITE_SIZE", "TCC_HIT_sum"):
+    for k, d in counters(name).items():
+        pmc.setdefault(k, {}).update(d)
+bench = json.loads(open(f"{out}/bench.json").read().strip().splitlines()[-1])
+summary = {"tag": tag, "bench": bench, "kernels": stats, "pmc_per_launch": pmc}
+for k, d in pmc.items():
+    # FETCH_SIZE / WRITE_SIZE are reported in KiB.  On gfx950 FETCH_SIZE counts 64 B per 128-B
+    # request of a wide coalesced read, i.e. half the bytes; both raw and doubled are kept.
+    if "FETCH_SIZE" in d and "WRITE_SIZE" in d:
+        d["hbm_read_bytes_raw"] = d["FETCH_SIZE"] * 1024
+        d["hbm_read_bytes_x2"] = d["FETCH_SIZE"] * 2048
+        d["hbm_write_bytes"] = d["WRITE_SIZE"] * 1024
+    if "TCC_HIT_sum" in d:
+        d["l2_hit_rate"] = d["TCC_HIT_sum"] / (d["TCC_HIT_sum"] + d["TCC_MISS_sum"])
+json.dump(summary, open(f"{out}/summary_{tag}.json", "w"), indent=1)
+with open(f"{out}/summary_{tag}.md", "w") as f:
+    f.write(f"# rocprofv3 summary `{tag}`\n\nbench line (un-profiled run, same command):\n\n```\n{json.dumps(bench)}\n```\n\n")
+    f.write("## kernel trace (`rocprofv3 --kernel-trace --stats`)\n\n| kernel | calls | avg ms | min ms | max ms |\n|---|---|---|---|---|\n")
+    for r in stats:
+        f.write(f"| `{r['kernel']}` | {r['calls']} | {r['avg_ms']:.4f} | {r['min_ms']:.4f} | {r['max_ms']:.4f} |\n")
+    f.write("\n## counters per launch (`rocprofv3 --pmc`, one pass per group)\n\n")
+    f.write("| kernel | FETCH_SIZE KiB | WRITE_SIZE KiB | HBM read B (x2 corrected) | HBM write B | L2 hit rate | TCC_EA0_RDREQ | TCC_EA0_WRREQ |\n|---|---|---|---|---|---|---|---|\n")
+    for k, d in pmc.items():
+        f.write(f"| `{k}` | {d.get('FETCH_SIZE', 0):.0f} | {d.get('WRITE_SIZE', 0):.0f} | {d.get('hbm_read_bytes_x2', 0):.3e} | {d.get('hbm_write_bytes', 0):.3e} | {d.get('l2_hit_rate', 0):.3f} | {d.get('TCC_EA0_RDREQ_sum', 0):.3e} | {d.get('TCC_EA0_WRREQ_sum', 0):.3e} |\n")
+print(open(f"{out}/summary_{tag}.md").read())
