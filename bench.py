@@ -79,6 +79,8 @@ def main() -> None:
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch override")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fwd-only", action="store_true")
+    ap.add_argument("--no-head-major", action="store_true",
+                    help="gather from the (N,S,M,D) value as given instead of a per-head copy")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -112,6 +114,13 @@ def main() -> None:
     )
     fwd = torch.ops.unipercept.ms_deform_attn_fwd
     bwd = torch.ops.unipercept.ms_deform_attn_bwd
+    to_head_major = torch.ops.unipercept.ms_deform_attn_value_head_major
+    from unipercept_amd import _lib
+
+    # same sequence as MultiScaleDeformAttnFunction: one per-head re-layout of value per step,
+    # shared by the forward and the backward (it is inside the timed region)
+    head_major = not args.no_head_major and _ops.head_major_supported(value, loc)
+    flags = _lib.FLAG_VALUE_HEAD_MAJOR if head_major else 0
 
     bucket = None
     comm_stream = None
@@ -127,14 +136,15 @@ def main() -> None:
     def step(i: int | None) -> None:
         if i is not None:
             ev[i][0].record()
-        out = fwd(value, shapes, lsi, loc, attn, 0)
+        v = to_head_major(value) if head_major else value
+        out = fwd(v, shapes, lsi, loc, attn, flags)
         if i is not None:
             ev[i][1].record()
         if not args.fwd_only:
-            bwd(grad_out, value, shapes, lsi, loc, attn, 0)
+            bwd(grad_out, v, shapes, lsi, loc, attn, flags)
         if i is not None:
             ev[i][2].record()
-        del out
+        del out, v
         if bucket is not None:
             # the gradient bucket of this step is reduced while the next step computes
             comm_stream.wait_stream(torch.cuda.current_stream(device))
@@ -208,6 +218,9 @@ def main() -> None:
                 "queries": w.positions,
                 "loc_dtype": w.loc_dtype or w.dtype,
                 "location_distribution": args.dist,
+                "value_gather_layout": "per-head copy (N,M,S,D), re-laid out inside the step"
+                if head_major
+                else "as given (N,S,M,D)",
                 "sampled_points_per_gpu_step": pts_per_gpu,
                 "parallelism": f"dp{world}",
                 "collective": None

@@ -142,3 +142,34 @@ def test_fp16_generic_and_tuned():
     got = _hip(value, shapes, lsi, loc, attn, grad_out)  # fp16 value, fp32 loc/attn
     for g, w_ in zip(got, want):
         assert np.abs(g - w_).max() / (np.abs(w_).max() + 1e-30) <= 2**-9
+
+
+def test_head_major_layout_matches_position_major(monkeypatch):
+    """The per-head value copy is a pure re-layout: identical results either way."""
+    from unipercept_amd import _lib
+    from unipercept_amd.deform_attn import _ops
+
+    n, m, d, lq, levels, p = MID["enc_L3P4"]
+    value, shapes, lsi, loc, attn, grad_out = make_inputs(
+        n, m, d, lq, levels, p, dtype=torch.float32, seed=21, device="cuda"
+    )
+    assert _ops.head_major_supported(value, loc)
+    vt = torch.ops.unipercept.ms_deform_attn_value_head_major(value)
+    assert vt.shape == (n, m, value.shape[1], d)
+    assert torch.equal(vt, value.permute(0, 2, 1, 3).contiguous())
+    fwd, bwd = torch.ops.unipercept.ms_deform_attn_fwd, torch.ops.unipercept.ms_deform_attn_bwd
+    hm = _lib.FLAG_VALUE_HEAD_MAJOR
+    assert torch.equal(fwd(value, shapes, lsi, loc, attn, 0), fwd(vt, shapes, lsi, loc, attn, hm))
+    a = bwd(grad_out, value, shapes, lsi, loc, attn, 0)
+    b = bwd(grad_out, vt, shapes, lsi, loc, attn, hm)
+    assert a[0].shape == b[0].shape == value.shape
+    for x, y in zip(a, b):
+        assert (x - y).abs().max() <= 1e-6
+    # a shape without a tuned path refuses the flag instead of misreading the tensor
+    v30 = torch.rand(1, 640, 2, 30, device="cuda")
+    sh = torch.tensor([[32, 16], [16, 8]], device="cuda")
+    lo = torch.rand(1, 2, 2, 2, 2, 2, device="cuda")
+    at = torch.rand(1, 2, 2, 2, 2, device="cuda")
+    assert not _ops.head_major_supported(v30, lo)
+    with pytest.raises(RuntimeError, match="head-major"):
+        fwd(v30.permute(0, 2, 1, 3).contiguous(), sh, level_start_index(sh), lo, at, hm)

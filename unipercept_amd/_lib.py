@@ -17,6 +17,7 @@ F32, F64, BF16, F16 = 0, 1, 2, 3
 FLAG_DETERMINISTIC = 1
 FLAG_GENERIC = 2
 FLAG_ATOMIC_SCATTER = 4
+FLAG_VALUE_HEAD_MAJOR = 8
 
 # every symbol include/msda.h declares
 EXPORTS = (
@@ -24,6 +25,8 @@ EXPORTS = (
     "msda_error_string",
     "msda_check_im2col_step",
     "msda_forward",
+    "msda_head_major_supported",
+    "msda_value_relayout",
     "msda_backward_workspace_bytes",
     "msda_backward",
 )
@@ -46,6 +49,10 @@ def _declare(lib: ctypes.CDLL) -> None:
     lib.msda_check_im2col_step.argtypes = [c_int, c_int]
     lib.msda_forward.restype = c_int
     lib.msda_forward.argtypes = [c_vp] * 6 + [c_int] * 7 + [c_int, c_int, c_int, c_vp]
+    lib.msda_head_major_supported.restype = c_int
+    lib.msda_head_major_supported.argtypes = [c_int] * 9
+    lib.msda_value_relayout.restype = c_int
+    lib.msda_value_relayout.argtypes = [c_vp, c_vp] + [c_int] * 6 + [c_vp]
     lib.msda_backward_workspace_bytes.restype = c_sz
     lib.msda_backward_workspace_bytes.argtypes = [c_int] * 7 + [c_int, c_int, c_int]
     lib.msda_backward.restype = c_int

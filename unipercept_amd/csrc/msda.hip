@@ -150,6 +150,7 @@ const char* msda_error_string(int code) {
     case MSDA_EWORKSPACE: return "msda: workspace missing, misaligned or too small";
     case MSDA_ESTEP: return "msda: im2col_step must be >= 1 and min(N, im2col_step) must divide N";
     case MSDA_ELEVELS: return "msda: too many levels/points (L <= 16, L*P <= 128)";
+    case MSDA_ELAYOUT: return "msda: head-major value layout is not supported for this shape/path";
     default:
       return code > 0 ? hipGetErrorString(static_cast<hipError_t>(code)) : "msda: unknown error";
   }
@@ -176,9 +177,11 @@ int msda_forward(const void* value, const int64_t* shapes_dev, const int64_t* ls
 
   if (!(flags & MSDA_FLAG_GENERIC)) {
     const int t = tuned_forward(value, shapes_dev, lsi_dev, loc, attn, out, N, S, M, D, Lq, L, P,
-                                dtype_val, dtype_loc, stream);
+                                dtype_val, dtype_loc, (flags & MSDA_FLAG_VALUE_HEAD_MAJOR) != 0,
+                                stream);
     if (t != kNotTuned) return t;
   }
+  if (flags & MSDA_FLAG_VALUE_HEAD_MAJOR) return MSDA_ELAYOUT;
   switch (dtype_val) {
     case MSDA_F32:
       return fwd_generic<float, float>(value, shapes_dev, lsi_dev, loc, attn, out, d, stream);
@@ -194,6 +197,32 @@ int msda_forward(const void* value, const int64_t* shapes_dev, const int64_t* ls
                  : fwd_generic<f16_t, f16_t>(value, shapes_dev, lsi_dev, loc, attn, out, d, stream);
   }
   return MSDA_EDTYPE;
+}
+
+int msda_head_major_supported(int N, int S, int M, int D, int Lq, int L, int P, int dtype_val,
+                              int dtype_loc) {
+  if (check_common(N, S, M, D, Lq, L, P, dtype_val, dtype_loc) != MSDA_OK) return 0;
+  return head_major_supported(N, S, M, D, Lq, L, P, dtype_val, dtype_loc) ? 1 : 0;
+}
+
+int msda_value_relayout(const void* src, void* dst, int N, int S, int M, int D, int dtype_val,
+                        int to_head_major, void* hip_stream) {
+  if (!src || !dst) return MSDA_ENULL;
+  if (N < 1 || S < 1 || M < 1 || D < 1) return MSDA_ESHAPE;
+  const size_t e = elem_size(dtype_val);
+  if (e == 0) return MSDA_EDTYPE;
+  if ((static_cast<size_t>(D) * e) % 16 != 0) return MSDA_ELAYOUT;
+  if (!aligned(src, 16) || !aligned(dst, 16)) return MSDA_EALIGN;
+  const int chunks = static_cast<int>(static_cast<size_t>(D) * e / 16);
+  const int64_t rows = static_cast<int64_t>(N) * S * M;
+  const int64_t blocks = (rows * chunks + 255) / 256;
+  const unsigned grid = static_cast<unsigned>(blocks < 16384 ? blocks : 16384);
+  // to head-major: src (N,S,M,.) -> dst (N,M,S,.); back: src (N,M,S,.) -> dst (N,S,M,.)
+  hipLaunchKernelGGL(relayout_rows_kernel, dim3(grid), dim3(256), 0,
+                     static_cast<hipStream_t>(hip_stream), static_cast<const uint4*>(src),
+                     static_cast<uint4*>(dst), rows, to_head_major ? S : M, to_head_major ? M : S,
+                     chunks);
+  return launch_status();
 }
 
 size_t msda_backward_workspace_bytes(int N, int S, int M, int D, int Lq, int L, int P,
@@ -235,9 +264,11 @@ int msda_backward(const void* grad_out, const void* value, const int64_t* shapes
   if (!det && !(flags & MSDA_FLAG_GENERIC)) {
     const int t = tuned_backward(grad_out, value, shapes_dev, lsi_dev, loc, attn, grad_value,
                                  grad_loc, grad_attn, workspace, N, S, M, D, Lq, L, P, dtype_val,
-                                 dtype_loc, !(flags & MSDA_FLAG_ATOMIC_SCATTER), stream);
+                                 dtype_loc, !(flags & MSDA_FLAG_ATOMIC_SCATTER),
+                                 (flags & MSDA_FLAG_VALUE_HEAD_MAJOR) != 0, stream);
     if (t != kNotTuned) return t;
   }
+  if (flags & MSDA_FLAG_VALUE_HEAD_MAJOR) return MSDA_ELAYOUT;
 #define MSDA_BWD(VT, LT, GT)                                                                  \
   bwd_generic<VT, LT, GT>(grad_out, value, shapes_dev, lsi_dev, loc, attn, grad_value,        \
                           grad_loc, grad_attn, workspace, d, det, stream)

@@ -29,6 +29,7 @@
 namespace msda {
 
 constexpr int kNotTuned = INT32_MIN;
+constexpr int MSDA_TUNED_ELAYOUT = -8;  // = MSDA_ELAYOUT of the public header
 constexpr int kMaxLevelsTuned = 16;
 
 template <typename VT>
@@ -215,7 +216,7 @@ template <typename VT, typename LT, int G>
 __global__ __launch_bounds__(256) void fwd_tuned_kernel(
     const VT* __restrict__ value, const int64_t* __restrict__ shapes,
     const int64_t* __restrict__ lsi, const LT* __restrict__ loc, const LT* __restrict__ attn,
-    VT* __restrict__ out, int S, int M, int Lq, int L, int P) {
+    VT* __restrict__ out, int S, int M, int Lq, int L, int P, int head_major) {
   constexpr int CPL = Chunk<VT>::kCPL;
   constexpr int D = G * CPL;
   constexpr int GPB = 256 / G;  // queries per block
@@ -230,8 +231,9 @@ __global__ __launch_bounds__(256) void fwd_tuned_kernel(
   if (threadIdx.x < L) lv[threadIdx.x] = load_level(shapes, lsi, threadIdx.x, S);
   __syncthreads();
 
-  const uint32_t rowb = static_cast<uint32_t>(M) * D * sizeof(VT);
-  const uint32_t headb = static_cast<uint32_t>(m) * D * sizeof(VT);
+  // value is (N,S,M,D), or (N,M,S,D) when head_major: bytes between positions / to head m
+  const uint32_t rowb = static_cast<uint32_t>(head_major ? 1 : M) * D * sizeof(VT);
+  const uint32_t headb = static_cast<uint32_t>(m) * (head_major ? S : 1) * D * sizeof(VT);
   stage_chunk<LT, 2, false>(lv, loc, attn, lds, b, q0, nq, m, M, Lq, LP, P, rowb, headb, EmitCtx{});
   __syncthreads();
 
@@ -330,7 +332,7 @@ __global__ __launch_bounds__(256) void bwd_query_kernel(
     const int64_t* __restrict__ shapes, const int64_t* __restrict__ lsi,
     const LT* __restrict__ loc, const LT* __restrict__ attn, LT* __restrict__ grad_loc,
     LT* __restrict__ grad_attn, float* __restrict__ gv_acc, uint4* __restrict__ records,
-    uint2* __restrict__ dir, int S, int M, int Lq, int L, int P, BinPlan plan) {
+    uint2* __restrict__ dir, int S, int M, int Lq, int L, int P, int head_major, BinPlan plan) {
   constexpr int CPL = Chunk<VT>::kCPL;
   constexpr int D = G * CPL;
   constexpr int GPB = 256 / G;
@@ -347,8 +349,8 @@ __global__ __launch_bounds__(256) void bwd_query_kernel(
   if (threadIdx.x < L) lv[threadIdx.x] = load_level(shapes, lsi, threadIdx.x, S);
   __syncthreads();
 
-  const uint32_t rowb = static_cast<uint32_t>(M) * D * sizeof(VT);
-  const uint32_t headb = static_cast<uint32_t>(m) * D * sizeof(VT);
+  const uint32_t rowb = static_cast<uint32_t>(head_major ? 1 : M) * D * sizeof(VT);
+  const uint32_t headb = static_cast<uint32_t>(m) * (head_major ? S : 1) * D * sizeof(VT);
   uint4* stage = lds;
   const int stage_slots = GPB * group_stride_slots(LP, 3);
   uint32_t* tile_cnt = reinterpret_cast<uint32_t*>(lds + stage_slots);
@@ -776,17 +778,46 @@ inline bool make_bin_plan(int N, int S, int M, int D, int Lq, int L, int P, BinP
   return true;
 }
 
+// True when both the forward and the backward of this shape run on kernels that accept a
+// head-major (N,M,S,D) value tensor.
+inline bool head_major_supported(int N, int S, int M, int D, int Lq, int L, int P, int dtype_val,
+                                 int dtype_loc) {
+  int G;
+  BinPlan plan;
+  size_t a, b;
+  return tuned_shape_ok(N, S, M, D, Lq, L, P, dtype_val, dtype_loc, &G) &&
+         make_bin_plan(N, S, M, D, Lq, L, P, &plan, &a, &b);
+}
+
+// (N,S,M,D) <-> (N,M,S,D): rows of D*e bytes move whole, 16 bytes per lane
+__global__ __launch_bounds__(256) void relayout_rows_kernel(const uint4* __restrict__ src,
+                                                           uint4* __restrict__ dst, int64_t rows,
+                                                           int A, int B, int chunks) {
+  // src is (n, A, B, chunks), dst is (n, B, A, chunks)
+  const int64_t total = rows * chunks;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * 256;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; i < total; i += stride) {
+    const int c = static_cast<int>(i % chunks);
+    const int64_t row = i / chunks;  // destination row index: (n, b, a)
+    const int a = static_cast<int>(row % A);
+    const int bb = static_cast<int>(row / A % B);
+    const int64_t n = row / A / B;
+    dst[i] = src[((n * A + a) * B + bb) * chunks + c];
+  }
+}
+
 template <typename VT, typename LT>
 int tuned_forward_typed(const void* value, const int64_t* shapes, const int64_t* lsi,
                         const void* loc, const void* attn, void* out, int N, int S, int M, int Lq,
-                        int L, int P, int G, hipStream_t stream) {
+                        int L, int P, int G, bool head_major, hipStream_t stream) {
   const int GPB = 256 / G;
   const dim3 grid(static_cast<unsigned>((Lq + GPB - 1) / GPB) * M, N);
   const size_t lds = static_cast<size_t>(GPB) * group_stride_slots(L * P, 2) * 16;
 #define MSDA_TF(GG)                                                                             \
   hipLaunchKernelGGL((fwd_tuned_kernel<VT, LT, GG>), grid, dim3(256), lds, stream,              \
                      static_cast<const VT*>(value), shapes, lsi, static_cast<const LT*>(loc),   \
-                     static_cast<const LT*>(attn), static_cast<VT*>(out), S, M, Lq, L, P)
+                     static_cast<const LT*>(attn), static_cast<VT*>(out), S, M, Lq, L, P,        \
+                     head_major ? 1 : 0)
   switch (G) {
     case 4: MSDA_TF(4); break;
     case 8: MSDA_TF(8); break;
@@ -799,11 +830,12 @@ int tuned_forward_typed(const void* value, const int64_t* shapes, const int64_t*
 
 inline int tuned_forward(const void* value, const int64_t* shapes, const int64_t* lsi,
                          const void* loc, const void* attn, void* out, int N, int S, int M, int D,
-                         int Lq, int L, int P, int dtype_val, int dtype_loc, hipStream_t stream) {
+                         int Lq, int L, int P, int dtype_val, int dtype_loc, bool head_major,
+                         hipStream_t stream) {
   int G;
   if (!tuned_shape_ok(N, S, M, D, Lq, L, P, dtype_val, dtype_loc, &G)) return kNotTuned;
   if (!all_aligned16({value, out})) return kNotTuned;
-#define MSDA_ARGS value, shapes, lsi, loc, attn, out, N, S, M, Lq, L, P, G, stream
+#define MSDA_ARGS value, shapes, lsi, loc, attn, out, N, S, M, Lq, L, P, G, head_major, stream
   if (dtype_val == 0) return tuned_forward_typed<float, float>(MSDA_ARGS);
   if (dtype_val == 2)
     return dtype_loc == 0 ? tuned_forward_typed<bf16_t, float>(MSDA_ARGS)
@@ -829,7 +861,7 @@ template <typename VT, typename LT>
 int tuned_backward_typed(const void* grad_out, const void* value, const int64_t* shapes,
                          const int64_t* lsi, const void* loc, const void* attn, void* grad_value,
                          void* grad_loc, void* grad_attn, void* workspace, int N, int S, int M,
-                         int D, int Lq, int L, int P, int G, bool allow_binned,
+                         int D, int Lq, int L, int P, int G, bool allow_binned, bool head_major,
                          hipStream_t stream) {
   const int GPB = 256 / G;
   const int LP = L * P;
@@ -853,7 +885,8 @@ int tuned_backward_typed(const void* grad_out, const void* value, const int64_t*
                      static_cast<const VT*>(grad_out), static_cast<const VT*>(value), shapes,    \
                      lsi, static_cast<const LT*>(loc), static_cast<const LT*>(attn),             \
                      static_cast<LT*>(grad_loc), static_cast<LT*>(grad_attn),                    \
-                     static_cast<float*>(nullptr), records, dir, S, M, Lq, L, P, plan);          \
+                     static_cast<float*>(nullptr), records, dir, S, M, Lq, L, P,                 \
+                     head_major ? 1 : 0, plan);                                                  \
   hipLaunchKernelGGL((bwd_tile_kernel<VT, GG>), tgrid, dim3(256), tlds, stream,                  \
                      static_cast<const VT*>(grad_out), shapes, lsi, records, dir,                \
                      static_cast<VT*>(grad_value), S, M, Lq, L, plan)
@@ -867,7 +900,9 @@ int tuned_backward_typed(const void* grad_out, const void* value, const int64_t*
     return e == hipSuccess ? 0 : static_cast<int>(e);
   }
 
-  // fp32-atomic fallback (very long sequences)
+  // fp32-atomic fallback (very long sequences); it indexes grad_value with the value offsets,
+  // so it only takes the position-major layout
+  if (head_major) return MSDA_TUNED_ELAYOUT;
   plan.qb = 256;
   plan.n_qblocks = (Lq + plan.qb - 1) / plan.qb;
   plan.n_tiles = 0;
@@ -885,7 +920,7 @@ int tuned_backward_typed(const void* grad_out, const void* value, const int64_t*
                      lsi, static_cast<const LT*>(loc), static_cast<const LT*>(attn),             \
                      static_cast<LT*>(grad_loc), static_cast<LT*>(grad_attn), acc,               \
                      static_cast<uint4*>(nullptr), static_cast<uint2*>(nullptr), S, M, Lq, L, P, \
-                     plan)
+                     0, plan)
   switch (G) {
     case 4: MSDA_TB(4); break;
     case 8: MSDA_TB(8); break;
@@ -910,13 +945,13 @@ inline int tuned_backward(const void* grad_out, const void* value, const int64_t
                           const int64_t* lsi, const void* loc, const void* attn, void* grad_value,
                           void* grad_loc, void* grad_attn, void* workspace, int N, int S, int M,
                           int D, int Lq, int L, int P, int dtype_val, int dtype_loc,
-                          bool allow_binned, hipStream_t stream) {
+                          bool allow_binned, bool head_major, hipStream_t stream) {
   int G;
   if (!tuned_shape_ok(N, S, M, D, Lq, L, P, dtype_val, dtype_loc, &G)) return kNotTuned;
   if (!all_aligned16({value, grad_out, grad_value, workspace})) return kNotTuned;
 #define MSDA_ARGS                                                                               \
   grad_out, value, shapes, lsi, loc, attn, grad_value, grad_loc, grad_attn, workspace, N, S, M, \
-      D, Lq, L, P, G, allow_binned, stream
+      D, Lq, L, P, G, allow_binned, head_major, stream
   if (dtype_val == 0) return tuned_backward_typed<float, float>(MSDA_ARGS);
   if (dtype_val == 2)
     return dtype_loc == 0 ? tuned_backward_typed<bf16_t, float>(MSDA_ARGS)

@@ -40,6 +40,15 @@ def forward_flags() -> int:
     return _lib.FLAG_GENERIC if os.environ.get("MSDA_FORCE_GENERIC") == "1" else 0
 
 
+def use_head_major(value: torch.Tensor, sampling_locations: torch.Tensor, bwd_flags: int) -> bool:
+    """The fast path re-lays value out per head once and gathers from that copy in both passes."""
+    if os.environ.get("MSDA_NO_HEAD_MAJOR") == "1":
+        return False
+    if bwd_flags & (_lib.FLAG_GENERIC | _lib.FLAG_DETERMINISTIC | _lib.FLAG_ATOMIC_SCATTER):
+        return False
+    return value.is_cuda and _ops.head_major_supported(value, sampling_locations)
+
+
 class MultiScaleDeformAttnFunction(torch.autograd.Function):
     @staticmethod
     def forward(
@@ -56,9 +65,15 @@ class MultiScaleDeformAttnFunction(torch.autograd.Function):
             "im2col_step check",
         )
         ctx.im2col_step = int(im2col_step)
+        fflags = forward_flags()
+        bflags = backward_flags(value, sampling_locations)
+        ctx.head_major = use_head_major(value, sampling_locations, bflags)
+        if ctx.head_major:
+            # one re-layout serves both passes: the copy is what gets saved for the backward
+            value = _ops.ms_deform_attn_value_head_major(value)
+            fflags |= _lib.FLAG_VALUE_HEAD_MAJOR
         out = _ops.ms_deform_attn_fwd(
-            value, spatial_shapes, level_start_index, sampling_locations, attention_weights,
-            forward_flags(),
+            value, spatial_shapes, level_start_index, sampling_locations, attention_weights, fflags
         )
         ctx.save_for_backward(
             value, spatial_shapes, level_start_index, sampling_locations, attention_weights
@@ -71,9 +86,12 @@ class MultiScaleDeformAttnFunction(torch.autograd.Function):
         value, spatial_shapes, level_start_index, sampling_locations, attention_weights = (
             ctx.saved_tensors
         )
+        flags = backward_flags(value, sampling_locations)
+        if ctx.head_major:
+            flags |= _lib.FLAG_VALUE_HEAD_MAJOR
         grad_value, grad_loc, grad_attn = _ops.ms_deform_attn_bwd(
             grad_output, value, spatial_shapes, level_start_index, sampling_locations,
-            attention_weights, backward_flags(value, sampling_locations),
+            attention_weights, flags,
         )
         return grad_value, None, None, grad_loc, grad_attn, None
 

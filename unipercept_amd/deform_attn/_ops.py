@@ -24,8 +24,11 @@ _DTYPE_CODE = {
 _level_cache: dict[tuple, tuple] = {}
 
 
-def _dims(value, loc):
-    n, s, m, d = value.shape
+def _dims(value, loc, head_major: bool = False):
+    if head_major:
+        n, m, s, d = value.shape
+    else:
+        n, s, m, d = value.shape
     _, lq, _, l, p, _ = loc.shape
     return n, s, m, d, lq, l, p
 
@@ -57,13 +60,13 @@ def _check_levels(shapes: torch.Tensor, lsi: torch.Tensor, s: int) -> None:
     _level_cache[key] = (hw, st)
 
 
-def _validate(value, shapes, lsi, loc, attn):
+def _validate(value, shapes, lsi, loc, attn, head_major: bool = False):
     if value.dim() != 4 or loc.dim() != 6 or attn.dim() != 5 or loc.shape[-1] != 2:
         raise ValueError(
             "expected value (N,S,M,D), sampling_locations (N,Lq,M,L,P,2), attention_weights "
             f"(N,Lq,M,L,P); got {tuple(value.shape)}, {tuple(loc.shape)}, {tuple(attn.shape)}"
         )
-    n, s, m, d, lq, l, p = _dims(value, loc)
+    n, s, m, d, lq, l, p = _dims(value, loc, head_major)
     if loc.shape[0] != n or loc.shape[2] != m or tuple(attn.shape) != (n, lq, m, l, p):
         raise ValueError(
             f"inconsistent shapes: value {tuple(value.shape)}, sampling_locations "
@@ -86,9 +89,9 @@ def _validate(value, shapes, lsi, loc, attn):
             raise RuntimeError("all tensors must live on the same device")
 
 
-def _prepare(value, shapes, lsi, loc, attn):
+def _prepare(value, shapes, lsi, loc, attn, head_major: bool = False):
     """Returns contiguous, dtype-consistent tensors on value's device."""
-    _validate(value, shapes, lsi, loc, attn)
+    _validate(value, shapes, lsi, loc, attn, head_major)
     dev = value.device
     shapes = shapes.to(device=dev, dtype=torch.int64).contiguous()
     lsi = lsi.to(device=dev, dtype=torch.int64).contiguous()
@@ -101,7 +104,7 @@ def _prepare(value, shapes, lsi, loc, attn):
     loc = loc.to(ldt).contiguous()
     attn = attn.to(ldt).contiguous()
     value = value.contiguous()
-    _check_levels(shapes, lsi, value.shape[1])
+    _check_levels(shapes, lsi, value.shape[2 if head_major else 1])
     return value, shapes, lsi, loc, attn
 
 
@@ -119,10 +122,11 @@ def ms_deform_attn_fwd(
     flags: int,
 ) -> torch.Tensor:
     lib = _lib.load()
+    hm = bool(flags & _lib.FLAG_VALUE_HEAD_MAJOR)
     value, shapes, lsi, loc, attn = _prepare(
-        value, spatial_shapes, level_start_index, sampling_locations, attention_weights
+        value, spatial_shapes, level_start_index, sampling_locations, attention_weights, hm
     )
-    n, s, m, d, lq, l, p = _dims(value, loc)
+    n, s, m, d, lq, l, p = _dims(value, loc, hm)
     out = torch.empty((n, lq, m * d), dtype=value.dtype, device=value.device)
     with torch.cuda.device_of(value):
         rc = lib.msda_forward(
@@ -136,7 +140,8 @@ def ms_deform_attn_fwd(
 
 @ms_deform_attn_fwd.register_fake
 def _(value, spatial_shapes, level_start_index, sampling_locations, attention_weights, flags):
-    n, _, m, d = value.shape
+    n, d = value.shape[0], value.shape[3]
+    m = sampling_locations.shape[2]
     return value.new_empty((n, sampling_locations.shape[1], m * d))
 
 
@@ -152,14 +157,15 @@ def ms_deform_attn_bwd(
 ) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
     lib = _lib.load()
     loc_dtype, attn_dtype = sampling_locations.dtype, attention_weights.dtype
+    hm = bool(flags & _lib.FLAG_VALUE_HEAD_MAJOR)
     value, shapes, lsi, loc, attn = _prepare(
-        value, spatial_shapes, level_start_index, sampling_locations, attention_weights
+        value, spatial_shapes, level_start_index, sampling_locations, attention_weights, hm
     )
-    n, s, m, d, lq, l, p = _dims(value, loc)
+    n, s, m, d, lq, l, p = _dims(value, loc, hm)
     grad_output = grad_output.to(value.dtype).contiguous()
     if tuple(grad_output.shape) != (n, lq, m * d):
         raise ValueError(f"grad_output must be {(n, lq, m * d)}, got {tuple(grad_output.shape)}")
-    grad_value = torch.empty_like(value)
+    grad_value = torch.empty((n, s, m, d), dtype=value.dtype, device=value.device)
     grad_loc = torch.empty_like(loc)
     grad_attn = torch.empty_like(attn)
     vcode, lcode = _DTYPE_CODE[value.dtype], _DTYPE_CODE[loc.dtype]
@@ -180,8 +186,49 @@ def ms_deform_attn_bwd(
 
 @ms_deform_attn_bwd.register_fake
 def _(grad_output, value, spatial_shapes, level_start_index, sampling_locations, attention_weights, flags):
+    gv = value.transpose(1, 2) if flags & _lib.FLAG_VALUE_HEAD_MAJOR else value
     return (
-        torch.empty_like(value),
+        torch.empty_like(gv, memory_format=torch.contiguous_format),
         torch.empty_like(sampling_locations),
         torch.empty_like(attention_weights),
+    )
+
+
+@torch.library.custom_op("unipercept::ms_deform_attn_value_head_major", mutates_args=())
+def ms_deform_attn_value_head_major(value: torch.Tensor) -> torch.Tensor:
+    """(N,S,M,D) -> a new contiguous (N,M,S,D) tensor (one slab per head), by a HIP row copy."""
+    lib = _lib.load()
+    if value.dim() != 4 or value.dtype not in _DTYPE_CODE:
+        raise ValueError(f"expected a floating (N,S,M,D) tensor, got {tuple(value.shape)} {value.dtype}")
+    if value.device.type != "cuda":
+        raise RuntimeError("ms_deform_attn_value_head_major runs only on a ROCm GPU")
+    value = value.contiguous()
+    n, s, m, d = value.shape
+    out = torch.empty((n, m, s, d), dtype=value.dtype, device=value.device)
+    with torch.cuda.device_of(value):
+        rc = lib.msda_value_relayout(
+            value.data_ptr(), out.data_ptr(), n, s, m, d, _DTYPE_CODE[value.dtype], 1,
+            _stream_ptr(value.device),
+        )
+    _lib.check(rc, "msda_value_relayout")
+    return out
+
+
+@ms_deform_attn_value_head_major.register_fake
+def _(value):
+    n, s, m, d = value.shape
+    return value.new_empty((n, m, s, d))
+
+
+def head_major_supported(value: torch.Tensor, sampling_locations: torch.Tensor) -> bool:
+    """Whether forward and backward of this problem take a head-major value tensor."""
+    if value.dtype not in _DTYPE_CODE or value.dim() != 4 or sampling_locations.dim() != 6:
+        return False
+    n, s, m, d, lq, l, p = _dims(value, sampling_locations)
+    vdt = value.dtype
+    ldt = sampling_locations.dtype
+    if not (ldt == torch.float32 and vdt in (torch.bfloat16, torch.float16)):
+        ldt = vdt
+    return bool(
+        _lib.load().msda_head_major_supported(n, s, m, d, lq, l, p, _DTYPE_CODE[vdt], _DTYPE_CODE[ldt])
     )
