@@ -313,7 +313,10 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t* data, int n, 
 }
 
 // positions per destination tile, by head dim
-__host__ __device__ constexpr int tile_positions(int D) { return D <= 32 ? 256 : 128; }
+#ifndef MSDA_TS_SMALL_D
+#define MSDA_TS_SMALL_D 256
+#endif
+__host__ __device__ constexpr int tile_positions(int D) { return D <= 32 ? MSDA_TS_SMALL_D : 128; }
 
 struct BinPlan {
   int ts_shift;     // log2 of the tile size in positions
@@ -535,7 +538,6 @@ __global__ __launch_bounds__(256) void bwd_tile_kernel(
   constexpr int PPG = TS / PG;                // positions owned by one entry group
   extern __shared__ uint4 lds[];
   __shared__ LevelInfo lv[kMaxLevelsTuned];
-  __shared__ uint32_t wsum[4];
   __shared__ uint32_t n_runs_s, total_s;
 
   char* gstage = reinterpret_cast<char*>(lds);                                // R rows
@@ -632,23 +634,31 @@ __global__ __launch_bounds__(256) void bwd_tile_kernel(
       }
     }
     __syncthreads();
-    // ---- D: exclusive scan of the per-position counts (TS <= 256: one per thread) ----
+    // ---- D: exclusive scan of the per-position counts.  Every wave scans the whole array
+    //         redundantly (K consecutive counters per lane), so no cross-wave step is needed;
+    //         wave w then publishes the quarter of the result its lanes 16w..16w+15 hold ----
     {
-      const uint32_t c = threadIdx.x < static_cast<unsigned>(TS) ? cnt[threadIdx.x] : 0u;
-      const uint32_t x = wave_inclusive_scan(c);
-      if (wlane == 63) wsum[wave] = x;
-      __syncthreads();
-      uint32_t pre = 0;
+      constexpr int K = TS / 64;
+      uint32_t c[K];
+      uint32_t local = 0;
 #pragma unroll
-      for (int w = 0; w < 4; ++w) pre += (w < wave) ? wsum[w] : 0u;
-      if (threadIdx.x < static_cast<unsigned>(TS)) {
-        start[threadIdx.x] = pre + x - c;
-        cursor[threadIdx.x] = pre + x - c;
-        cnt[threadIdx.x] = 0;  // ready for the next slice
+      for (int j = 0; j < K; ++j) {
+        c[j] = cnt[wlane * K + j];
+        local += c[j];
       }
-      if (threadIdx.x == 255) start[TS] = pre + x;
+      uint32_t run = wave_inclusive_scan(local) - local;
+      if ((wlane >> 4) == wave) {
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+          start[wlane * K + j] = run;
+          cursor[wlane * K + j] = run;
+          run += c[j];
+        }
+        if (wlane == 63) start[TS] = run;
+      }
     }
     __syncthreads();
+    for (int i = threadIdx.x; i < TS; i += 256) cnt[i] = 0;  // ready for the next slice
     // ---- E: fill the buckets ----
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -754,7 +764,7 @@ inline bool all_aligned16(std::initializer_list<const void*> ps) {
 inline bool make_bin_plan(int N, int S, int M, int D, int Lq, int L, int P, BinPlan* plan,
                           size_t* dir_bytes, size_t* rec_bytes) {
   if (D > 64) return false;                  // the LDS row stage of a slice is 256 * D * 4 B
-  const int ts_shift = tile_positions(D) == 256 ? 8 : 7;
+  const int ts_shift = tile_positions(D) == 512 ? 9 : tile_positions(D) == 256 ? 8 : 7;
   const int TS = 1 << ts_shift;
   const int64_t n_tiles = (static_cast<int64_t>(S) + TS - 1) / TS;
   const int qb = 256;
