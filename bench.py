@@ -101,8 +101,12 @@ def main() -> None:
 
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    # under torch.distributed.run the process group is set up even for one rank, so that the
+    # collective path can be rehearsed on a single GPU
+    distributed = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group("nccl", device_id=device)
 
     from unipercept_amd.deform_attn import _ops  # loads libmsda.so (raises if missing)
@@ -124,7 +128,7 @@ def main() -> None:
 
     bucket = None
     comm_stream = None
-    if world > 1:
+    if distributed:
         n_params = harness.layer_param_count(w.heads * w.head_dim, w.heads, w.n_levels, w.points)
         bucket = harness.FlatGradBucket([n_params], device)
         bucket.flat.normal_()
@@ -153,8 +157,8 @@ def main() -> None:
 
     def fence() -> None:
         torch.cuda.synchronize(device)
-        if world > 1:
-            dist.barrier()
+        if distributed:
+            dist.barrier(device_ids=[local_rank])
             torch.cuda.synchronize(device)
 
     for _ in range(args.warmup):
@@ -165,7 +169,7 @@ def main() -> None:
         step(i)
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if distributed:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -224,7 +228,7 @@ def main() -> None:
                 "sampled_points_per_gpu_step": pts_per_gpu,
                 "parallelism": f"dp{world}",
                 "collective": None
-                if world == 1
+                if not distributed
                 else f"all_reduce(sum)/world of one flat fp32 bucket of {bucket.flat.numel()} "
                 "layer-parameter gradients per step, RCCL, side stream",
             },
@@ -253,8 +257,8 @@ def main() -> None:
             line["cpu_baseline"] = cpu_baseline(threads)
         print(json.dumps(line), flush=True)
 
-    if world > 1:
-        dist.barrier()
+    if distributed:
+        dist.barrier(device_ids=[local_rank])
         dist.destroy_process_group()
 
 

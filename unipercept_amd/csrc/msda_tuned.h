@@ -601,6 +601,7 @@ __global__ __launch_bounds__(256) void bwd_tile_kernel(
     if (run < n_runs) rec_next = slab_records[run_base[run] + off];
 
     // ---- B: grad_out rows of this wave's 64 record slots, global -> LDS ----
+    if (!(plan.ablate & 64))
 #pragma unroll
     for (int k = 0; k < G; ++k) {
       const int src = k * RPI + wlane / G;  // lane of the wave that holds the row's record
@@ -615,7 +616,7 @@ __global__ __launch_bounds__(256) void bwd_tile_kernel(
     }
 
     // ---- C: footprint of the thread's own record, count its in-tile corners per position ----
-    const bool have = rec.x != kRecInvalid;
+    const bool have = rec.x != kRecInvalid && !(plan.ablate & 32);
     uint32_t loc_pix[4];
     float loc_w[4];
     bool in_tile[4] = {false, false, false, false};

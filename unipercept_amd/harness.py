@@ -224,8 +224,6 @@ class FlatGradBucket:
         import torch.distributed as dist
 
         world = dist.get_world_size(group)
-        if world == 1:
-            return None
         self.flat.div_(world)
         return dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
 
