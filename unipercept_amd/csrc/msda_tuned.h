@@ -154,12 +154,13 @@ template <typename LT, int SLOTS, bool EMIT>
 __device__ __forceinline__ void stage_chunk(const LevelInfo* lv, const LT* __restrict__ loc,
                                             const LT* __restrict__ attn, uint4* stage, int b,
                                             int q_first, int nq, int m, int M, int Lq, int LP,
-                                            int P, uint32_t rowb, uint32_t headb,
-                                            const EmitCtx& emit) {
-  const int npts = nq * LP;
-  const int stride = group_stride_slots(LP, SLOTS);
+                                            int P, int i_first, int nI, int LPB, uint32_t rowb,
+                                            uint32_t headb, const EmitCtx& emit) {
+  // points i_first .. i_first + nI - 1 of every query; LDS lists are laid out for LPB points
+  const int npts = nq * nI;
+  const int stride = group_stride_slots(LPB, SLOTS);
   for (int t = threadIdx.x; t < npts; t += 256) {
-    const int g = t / LP, i = t - g * LP, l = i / P;
+    const int g = t / nI, ii = t - g * nI, i = i_first + ii, l = i / P;
     const LevelInfo L_ = lv[l];
     const int64_t idx = ((static_cast<int64_t>(b) * Lq + q_first + g) * M + m) * LP + i;
     const float x = Elem<LT>::load(loc + 2 * idx);
@@ -175,7 +176,7 @@ __device__ __forceinline__ void stage_chunk(const LevelInfo* lv, const LT* __res
     orec.y = (static_cast<uint32_t>(L_.start + f.pix[1]) * rowb + headb) | (f.valid[1] ? 1u : 0u);
     orec.z = (static_cast<uint32_t>(L_.start + f.pix[2]) * rowb + headb) | (f.valid[2] ? 1u : 0u);
     orec.w = (static_cast<uint32_t>(L_.start + f.pix[3]) * rowb + headb) | (f.valid[3] ? 1u : 0u);
-    uint4* dst = stage + g * stride + SLOTS * i;
+    uint4* dst = stage + g * stride + SLOTS * ii;
     dst[0] = wrec;
     dst[1] = orec;
     if constexpr (SLOTS == 3) {
@@ -216,7 +217,7 @@ template <typename VT, typename LT, int G>
 __global__ __launch_bounds__(256) void fwd_tuned_kernel(
     const VT* __restrict__ value, const int64_t* __restrict__ shapes,
     const int64_t* __restrict__ lsi, const LT* __restrict__ loc, const LT* __restrict__ attn,
-    VT* __restrict__ out, int S, int M, int Lq, int L, int P, int head_major) {
+    VT* __restrict__ out, int S, int M, int Lq, int L, int P, int LPB, int head_major) {
   constexpr int CPL = Chunk<VT>::kCPL;
   constexpr int D = G * CPL;
   constexpr int GPB = 256 / G;  // queries per block
@@ -234,34 +235,42 @@ __global__ __launch_bounds__(256) void fwd_tuned_kernel(
   // value is (N,S,M,D), or (N,M,S,D) when head_major: bytes between positions / to head m
   const uint32_t rowb = static_cast<uint32_t>(head_major ? 1 : M) * D * sizeof(VT);
   const uint32_t headb = static_cast<uint32_t>(m) * (head_major ? S : 1) * D * sizeof(VT);
-  stage_chunk<LT, 2, false>(lv, loc, attn, lds, b, q0, nq, m, M, Lq, LP, P, rowb, headb, EmitCtx{});
-  __syncthreads();
-
   const int g = threadIdx.x / G, lane = threadIdx.x % G;
-  if (g >= nq) return;
+  const bool live = g < nq;
   const char* vb = reinterpret_cast<const char*>(value) +
                    static_cast<int64_t>(b) * S * M * D * static_cast<int64_t>(sizeof(VT));
   const uint32_t lane_b = lane * 16;
-  const uint4* rec = lds + g * group_stride_slots(LP, 2);
+  const uint4* rec = lds + g * group_stride_slots(LPB, 2);
 
   float acc[CPL];
 #pragma unroll
   for (int c = 0; c < CPL; ++c) acc[c] = 0.f;
 
+  // the points of a query are staged LPB at a time (all of them at once for the usual L*P)
+  for (int ib = 0; ib < LP; ib += LPB) {
+    const int nI = min(LPB, LP - ib);
+    if (ib > 0) __syncthreads();
+    stage_chunk<LT, 2, false>(lv, loc, attn, lds, b, q0, nq, m, M, Lq, LP, P, ib, nI, LPB, rowb,
+                              headb, EmitCtx{});
+    __syncthreads();
+    if (live) {
 #pragma unroll 4
-  for (int i = 0; i < LP; ++i) {
-    const uint4 wr = rec[2 * i], orr = rec[2 * i + 1];
-    const float w[4] = {__uint_as_float(wr.x), __uint_as_float(wr.y), __uint_as_float(wr.z),
-                        __uint_as_float(wr.w)};
-    const uint32_t o[4] = {orr.x & ~15u, orr.y & ~15u, orr.z & ~15u, orr.w & ~15u};
-    float v[4][CPL];
+      for (int i = 0; i < nI; ++i) {
+        const uint4 wr = rec[2 * i], orr = rec[2 * i + 1];
+        const float w[4] = {__uint_as_float(wr.x), __uint_as_float(wr.y), __uint_as_float(wr.z),
+                            __uint_as_float(wr.w)};
+        const uint32_t o[4] = {orr.x & ~15u, orr.y & ~15u, orr.z & ~15u, orr.w & ~15u};
+        float v[4][CPL];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) Chunk<VT>::load(vb + (o[k] + lane_b), v[k]);
+        for (int k = 0; k < 4; ++k) Chunk<VT>::load(vb + (o[k] + lane_b), v[k]);
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
+        for (int k = 0; k < 4; ++k)
 #pragma unroll
-      for (int c = 0; c < CPL; ++c) acc[c] = fmaf(w[k], v[k][c], acc[c]);
+          for (int c = 0; c < CPL; ++c) acc[c] = fmaf(w[k], v[k][c], acc[c]);
+      }
+    }
   }
+  if (!live) return;
   const int64_t triple = (static_cast<int64_t>(b) * Lq + q0 + g) * M + m;
   Chunk<VT>::store(reinterpret_cast<char*>(out) + (triple * D + lane * CPL) * sizeof(VT), acc);
 }
@@ -335,7 +344,8 @@ __global__ __launch_bounds__(256) void bwd_query_kernel(
     const int64_t* __restrict__ shapes, const int64_t* __restrict__ lsi,
     const LT* __restrict__ loc, const LT* __restrict__ attn, LT* __restrict__ grad_loc,
     LT* __restrict__ grad_attn, float* __restrict__ gv_acc, uint4* __restrict__ records,
-    uint2* __restrict__ dir, int S, int M, int Lq, int L, int P, int head_major, BinPlan plan) {
+    uint2* __restrict__ dir, int S, int M, int Lq, int L, int P, int LPB, int head_major,
+    BinPlan plan) {
   constexpr int CPL = Chunk<VT>::kCPL;
   constexpr int D = G * CPL;
   constexpr int GPB = 256 / G;
@@ -355,7 +365,7 @@ __global__ __launch_bounds__(256) void bwd_query_kernel(
   const uint32_t rowb = static_cast<uint32_t>(head_major ? 1 : M) * D * sizeof(VT);
   const uint32_t headb = static_cast<uint32_t>(m) * (head_major ? S : 1) * D * sizeof(VT);
   uint4* stage = lds;
-  const int stage_slots = GPB * group_stride_slots(LP, 3);
+  const int stage_slots = GPB * group_stride_slots(LPB, 3);
   uint32_t* tile_cnt = reinterpret_cast<uint32_t*>(lds + stage_slots);
   uint32_t* tile_off = tile_cnt + plan.n_tiles;
   EmitCtx emit{};
@@ -404,26 +414,30 @@ __global__ __launch_bounds__(256) void bwd_query_kernel(
   const char* vb = reinterpret_cast<const char*>(value) + slab_elems * static_cast<int64_t>(sizeof(VT));
   const uint32_t lane_b = lane * 16;
 
-  for (int c0 = 0; c0 < qb_n; c0 += GPB) {
+  // chunks of GPB queries; inside a chunk the points are staged LPB at a time (LPB is a multiple
+  // of G, and all of L*P for the usual sizes)
+  for (int c0 = 0; c0 < qb_n; c0 += GPB)
+  for (int ib = 0; ib < LP; ib += LPB) {
     const int nq = min(GPB, qb_n - c0);
-    stage_chunk<LT, 3, MODE == 1>(lv, loc, attn, stage, b, qb0 + c0, nq, m, M, Lq, LP, P, rowb,
-                                  headb, emit);
+    const int nI = min(LPB, LP - ib);
+    stage_chunk<LT, 3, MODE == 1>(lv, loc, attn, stage, b, qb0 + c0, nq, m, M, Lq, LP, P, ib, nI,
+                                  LPB, rowb, headb, emit);
     __syncthreads();
     // lanes of groups past the end redo the last group (no writes) so that every DPP row is full
     const bool live = g < nq;
     const int gg = live ? g : nq - 1;
-    const uint4* r = stage + gg * group_stride_slots(LP, 3);
+    const uint4* r = stage + gg * group_stride_slots(LPB, 3);
     const int64_t triple = (static_cast<int64_t>(b) * Lq + qb0 + c0 + gg) * M + m;
     float go[CPL];
     Chunk<VT>::load(reinterpret_cast<const char*>(grad_out) + (triple * D + lane * CPL) * sizeof(VT), go);
 
     // G points per pass: after the pass lane j of the group keeps the results of point i0 + j, so
     // the group writes G consecutive grad_attn / grad_loc elements with one store each
-    for (int i0 = 0; i0 < LP; i0 += G) {
+    for (int i0 = 0; i0 < nI; i0 += G) {
       float keep_sv = 0.f, keep_sx = 0.f, keep_sy = 0.f;
 #pragma unroll
       for (int k = 0; k < G; ++k) {
-        const int i = min(i0 + k, LP - 1);  // a pass past the end redoes the last point (unused)
+        const int i = min(i0 + k, nI - 1);  // a pass past the end redoes the last point (unused)
         const uint4 wr = r[3 * i], orr = r[3 * i + 1], fr = r[3 * i + 2];
         const uint32_t oraw[4] = {orr.x, orr.y, orr.z, orr.w};
         const float lx = __uint_as_float(fr.x), ly = __uint_as_float(fr.y);
@@ -454,7 +468,7 @@ __global__ __launch_bounds__(256) void bwd_query_kernel(
                                __uint_as_float(wr.z), __uint_as_float(wr.w)};
 #pragma unroll
           for (int c4 = 0; c4 < 4; ++c4) {
-            if (live && aw[c4] != 0.f && i0 + k < LP) {
+            if (live && aw[c4] != 0.f && i0 + k < nI) {
               float* dst = gv_acc + slab_elems + o[c4] / sizeof(VT);
 #pragma unroll
               for (int c = 0; c < CPL; ++c) atomicAdd(dst + c, aw[c4] * go[c]);
@@ -477,8 +491,8 @@ __global__ __launch_bounds__(256) void bwd_query_kernel(
         }
       }
       const int i = i0 + lane;
-      if (i < LP && live && !(plan.ablate & 2)) {
-        const int64_t gi = triple * LP + i;
+      if (i < nI && live && !(plan.ablate & 2)) {
+        const int64_t gi = triple * LP + ib + i;
         Elem<LT>::store(grad_attn + gi, keep_sv);
         if constexpr (sizeof(LT) == 4) {
           *reinterpret_cast<float2*>(grad_loc + 2 * gi) = make_float2(keep_sx, keep_sy);
@@ -748,10 +762,18 @@ inline bool tuned_shape_ok(int N, int S, int M, int D, int Lq, int L, int P, int
   if (N > 65535) return false;
   const int GPB = 256 / G;
   if ((static_cast<int64_t>(Lq) + GPB - 1) / GPB * M > INT32_MAX) return false;
-  // LDS staging: (256/G) groups * (3*L*P | 1) slots * 16 B
-  if (static_cast<int64_t>(GPB) * group_stride_slots(L * P, 3) * 16 > 48 * 1024) return false;
   *G_out = G;
   return true;
+}
+
+// Points staged per pass: the largest multiple of G whose LDS lists (3 slots per point, 256/G
+// groups) stay within ~26 KB, or all L*P points when they fit.
+inline int stage_points_per_pass(int G, int LP) {
+  const int GPB = 256 / G;
+  int lpb = G;
+  while (lpb + G <= 4096 && static_cast<int64_t>(GPB) * group_stride_slots(lpb + G, 3) * 16 <= 26 * 1024)
+    lpb += G;
+  return LP <= lpb ? LP : lpb;
 }
 
 inline bool all_aligned16(std::initializer_list<const void*> ps) {
@@ -823,11 +845,12 @@ int tuned_forward_typed(const void* value, const int64_t* shapes, const int64_t*
                         int L, int P, int G, bool head_major, hipStream_t stream) {
   const int GPB = 256 / G;
   const dim3 grid(static_cast<unsigned>((Lq + GPB - 1) / GPB) * M, N);
-  const size_t lds = static_cast<size_t>(GPB) * group_stride_slots(L * P, 2) * 16;
+  const int LPB = stage_points_per_pass(G, L * P);
+  const size_t lds = static_cast<size_t>(GPB) * group_stride_slots(LPB, 2) * 16;
 #define MSDA_TF(GG)                                                                             \
   hipLaunchKernelGGL((fwd_tuned_kernel<VT, LT, GG>), grid, dim3(256), lds, stream,              \
                      static_cast<const VT*>(value), shapes, lsi, static_cast<const LT*>(loc),   \
-                     static_cast<const LT*>(attn), static_cast<VT*>(out), S, M, Lq, L, P,        \
+                     static_cast<const LT*>(attn), static_cast<VT*>(out), S, M, Lq, L, P, LPB,   \
                      head_major ? 1 : 0)
   switch (G) {
     case 4: MSDA_TF(4); break;
@@ -876,6 +899,7 @@ int tuned_backward_typed(const void* grad_out, const void* value, const int64_t*
                          hipStream_t stream) {
   const int GPB = 256 / G;
   const int LP = L * P;
+  const int LPB = stage_points_per_pass(G, LP);
   BinPlan plan{};
   size_t dir_b = 0, rec_b = 0;
   const bool binned = allow_binned && make_bin_plan(N, S, M, D, Lq, L, P, &plan, &dir_b, &rec_b);
@@ -885,7 +909,7 @@ int tuned_backward_typed(const void* grad_out, const void* value, const int64_t*
     uint2* dir = static_cast<uint2*>(workspace);
     uint4* records = reinterpret_cast<uint4*>(static_cast<char*>(workspace) + dir_b);
     const dim3 qgrid(static_cast<unsigned>(plan.n_qblocks) * M, N);
-    const size_t qlds = static_cast<size_t>(GPB) * group_stride_slots(LP, 3) * 16 +
+    const size_t qlds = static_cast<size_t>(GPB) * group_stride_slots(LPB, 3) * 16 +
                         static_cast<size_t>(plan.n_tiles) * 8;
     const dim3 tgrid(static_cast<unsigned>(plan.n_tiles) * M, N);
     const size_t TSz = static_cast<size_t>(1) << plan.ts_shift;
@@ -896,7 +920,7 @@ int tuned_backward_typed(const void* grad_out, const void* value, const int64_t*
                      static_cast<const VT*>(grad_out), static_cast<const VT*>(value), shapes,    \
                      lsi, static_cast<const LT*>(loc), static_cast<const LT*>(attn),             \
                      static_cast<LT*>(grad_loc), static_cast<LT*>(grad_attn),                    \
-                     static_cast<float*>(nullptr), records, dir, S, M, Lq, L, P,                 \
+                     static_cast<float*>(nullptr), records, dir, S, M, Lq, L, P, LPB,            \
                      head_major ? 1 : 0, plan);                                                  \
   hipLaunchKernelGGL((bwd_tile_kernel<VT, GG>), tgrid, dim3(256), tlds, stream,                  \
                      static_cast<const VT*>(grad_out), shapes, lsi, records, dir,                \
@@ -919,7 +943,7 @@ int tuned_backward_typed(const void* grad_out, const void* value, const int64_t*
   plan.n_tiles = 0;
   plan.ablate = 0;
   const dim3 grid(static_cast<unsigned>(plan.n_qblocks) * M, N);
-  const size_t lds = static_cast<size_t>(GPB) * group_stride_slots(LP, 3) * 16;
+  const size_t lds = static_cast<size_t>(GPB) * group_stride_slots(LPB, 3) * 16;
   const int64_t total = static_cast<int64_t>(N) * S * M * D;
   constexpr bool kDirect = sizeof(VT) == 4;
   float* acc = kDirect ? static_cast<float*>(grad_value) : static_cast<float*>(workspace);
@@ -931,7 +955,7 @@ int tuned_backward_typed(const void* grad_out, const void* value, const int64_t*
                      lsi, static_cast<const LT*>(loc), static_cast<const LT*>(attn),             \
                      static_cast<LT*>(grad_loc), static_cast<LT*>(grad_attn), acc,               \
                      static_cast<uint4*>(nullptr), static_cast<uint2*>(nullptr), S, M, Lq, L, P, \
-                     0, plan)
+                     LPB, 0, plan)
   switch (G) {
     case 4: MSDA_TB(4); break;
     case 8: MSDA_TB(8); break;
