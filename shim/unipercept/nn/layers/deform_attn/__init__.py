@@ -7,8 +7,15 @@ checkout; it forwards to the MI355X implementation in ``unipercept_amd``.
 from unipercept_amd.deform_attn import (  # noqa: F401
     MSDeformAttn,
     MultiScaleDeformAttnFunction,
+    MultiScaleFlashAttnFunction,
     ms_deform_attn,
     reference,
 )
 
-__all__ = ["MSDeformAttn", "MultiScaleDeformAttnFunction", "ms_deform_attn", "reference"]
+__all__ = [
+    "MSDeformAttn",
+    "MultiScaleDeformAttnFunction",
+    "MultiScaleFlashAttnFunction",
+    "ms_deform_attn",
+    "reference",
+]

@@ -96,6 +96,12 @@ def test_shim_module_path():
     import unipercept.nn.layers.deform_attn as shim
 
     assert shim.MultiScaleDeformAttnFunction is MultiScaleDeformAttnFunction
+    # the reference's test module imports these three names from the package (:6-10)
+    from unipercept.nn.layers.deform_attn import (  # noqa: F401
+        MultiScaleDeformAttnFunction as _a,
+        MultiScaleFlashAttnFunction as _b,
+        reference as _c,
+    )
     assert callable(shim.reference.deform_attn)
 
 

@@ -1,12 +1,18 @@
 """Drop-in for ``unipercept.nn.layers.deform_attn`` on MI355X.
 
 Exports what the reference's test imports from that package
-(tests/unipercept/nn/layers/test_nn_layers_deform_attn.py:6-10): ``MultiScaleDeformAttnFunction``
-and ``reference``; plus the functional alias ``ms_deform_attn`` and the ``MSDeformAttn`` layer.
+(tests/unipercept/nn/layers/test_nn_layers_deform_attn.py:6-10): ``MultiScaleDeformAttnFunction``,
+``MultiScaleFlashAttnFunction`` and ``reference``; plus the functional alias ``ms_deform_attn`` and the ``MSDeformAttn`` layer.
 """
 
 from . import reference
-from ._function import MultiScaleDeformAttnFunction, ms_deform_attn
+from ._function import MultiScaleDeformAttnFunction, MultiScaleFlashAttnFunction, ms_deform_attn
 from .layer import MSDeformAttn
 
-__all__ = ["MSDeformAttn", "MultiScaleDeformAttnFunction", "ms_deform_attn", "reference"]
+__all__ = [
+    "MSDeformAttn",
+    "MultiScaleDeformAttnFunction",
+    "MultiScaleFlashAttnFunction",
+    "ms_deform_attn",
+    "reference",
+]

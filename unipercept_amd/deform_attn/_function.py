@@ -96,6 +96,64 @@ class MultiScaleDeformAttnFunction(torch.autograd.Function):
         return grad_value, None, None, grad_loc, grad_attn, None
 
 
+class MultiScaleFlashAttnFunction(torch.autograd.Function):
+    """The packed-input entry point of the reference module
+    (tests/unipercept/nn/layers/test_nn_layers_deform_attn.py:105-111): locations and attention
+    weights arrive as one tensor ``cat([loc.flatten(-3), attn.flatten(-2)], -1)`` of shape
+    ``(N, Lq, M, L*P*3)``.  As in that test, the weights are used as given (the test passes
+    already normalised weights and compares with ``reference.deform_attn``), i.e. no softmax is
+    applied here.  Runs the same HIP kernels as ``MultiScaleDeformAttnFunction`` after unpacking;
+    the gradient comes back packed the same way.
+    """
+
+    @staticmethod
+    def forward(
+        ctx,
+        value: torch.Tensor,
+        spatial_shapes: torch.Tensor,
+        level_start_index: torch.Tensor,
+        packed: torch.Tensor,
+        im2col_step: int = 64,
+    ) -> torch.Tensor:
+        levels = int(spatial_shapes.shape[0])
+        if packed.dim() != 4 or packed.shape[-1] % (3 * levels) != 0:
+            raise ValueError(
+                f"packed locations+weights must be (N, Lq, M, L*P*3) with L = {levels}; got "
+                f"{tuple(packed.shape)}"
+            )
+        n, lq, m, width = packed.shape
+        points = width // (3 * levels)
+        lp = levels * points
+        loc = packed[..., : 2 * lp].reshape(n, lq, m, levels, points, 2)
+        attn = packed[..., 2 * lp :].reshape(n, lq, m, levels, points)
+        _lib.check(
+            _lib.load().msda_check_im2col_step(int(value.shape[0]), int(im2col_step)),
+            "im2col_step check",
+        )
+        fflags = forward_flags()
+        bflags = backward_flags(value, loc)
+        ctx.head_major = use_head_major(value, loc, bflags)
+        if ctx.head_major:
+            value = _ops.ms_deform_attn_value_head_major(value)
+            fflags |= _lib.FLAG_VALUE_HEAD_MAJOR
+        out = _ops.ms_deform_attn_fwd(value, spatial_shapes, level_start_index, loc, attn, fflags)
+        ctx.save_for_backward(value, spatial_shapes, level_start_index, loc, attn)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_output: torch.Tensor):
+        value, spatial_shapes, level_start_index, loc, attn = ctx.saved_tensors
+        flags = backward_flags(value, loc)
+        if ctx.head_major:
+            flags |= _lib.FLAG_VALUE_HEAD_MAJOR
+        grad_value, grad_loc, grad_attn = _ops.ms_deform_attn_bwd(
+            grad_output, value, spatial_shapes, level_start_index, loc, attn, flags
+        )
+        grad_packed = torch.cat((grad_loc.flatten(-3), grad_attn.flatten(-2)), dim=-1)
+        return grad_value, None, None, grad_packed, None
+
+
 def ms_deform_attn(
     value: torch.Tensor,
     spatial_shapes: torch.Tensor,
