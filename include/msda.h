@@ -116,9 +116,11 @@ int msda_value_relayout(const void* src, void* dst, int N, int S, int M, int D, 
  * Scratch the backward needs, in bytes (0 when none).  The binned grad_value path keeps its
  * scatter records (64 bytes per sampled point, worst case) and a tile directory there; the
  * atomic paths need an fp32 accumulation image of grad_value for 16-bit value dtypes.
+ * `shapes_host`: as for msda_backward (the size depends on it); pass the same value to both.
  */
 size_t msda_backward_workspace_bytes(int N, int S, int M, int D, int Lq, int L, int P,
-                                     int dtype_val, int dtype_loc, int flags);
+                                     int dtype_val, int dtype_loc, int flags,
+                                     const int64_t* shapes_host);
 
 /*
  * Backward: grad_value (N,S,M,D), grad_loc (N,Lq,M,L,P,2), grad_attn (N,Lq,M,L,P) for a given
@@ -129,12 +131,19 @@ size_t msda_backward_workspace_bytes(int N, int S, int M, int D, int Lq, int L, 
  * pre-zero).  `workspace` must hold msda_backward_workspace_bytes(...) bytes, 256-B aligned
  * (may be NULL when that is 0); its contents on entry are ignored and on return undefined.
  * grad_loc / grad_attn have dtype_loc, grad_value has dtype_val.
+ *
+ * `shapes_host` is optional (NULL allowed): a HOST copy of the L (H, W) pairs in `shapes_dev`.
+ * With it, and when `lsi_dev` is the exclusive prefix sum of H*W (the usual pyramid), the binned
+ * scatter cuts grad_value into 16-pixel-wide 2-D patches of a level instead of runs of the
+ * flattened sequence, which saves about a quarter of its record traffic.  It must match
+ * `shapes_dev`; a table that disagrees gives undefined grad_value contents (never an
+ * out-of-bounds access).  The pointer is only read during the call.
  */
 int msda_backward(const void* grad_out, const void* value, const int64_t* shapes_dev,
                   const int64_t* lsi_dev, const void* loc, const void* attn, void* grad_value,
                   void* grad_loc, void* grad_attn, void* workspace, size_t workspace_bytes, int N,
                   int S, int M, int D, int Lq, int L, int P, int dtype_val, int dtype_loc,
-                  int flags, void* hip_stream);
+                  int flags, const int64_t* shapes_host, void* hip_stream);
 
 #ifdef __cplusplus
 }

@@ -90,7 +90,7 @@ def _bwd(workspace=None, wbytes=0, dims=(2, 64, 2, 32, 64, 1, 2), dv=2, dl=2, fl
     p.update(kw)
     return _lib.load().msda_backward(
         p["grad_out"], p["value"], p["shapes"], p["lsi"], p["loc"], p["attn"], p["grad_value"],
-        p["grad_loc"], p["grad_attn"], workspace, wbytes, *dims, dv, dl, flags, None,
+        p["grad_loc"], p["grad_attn"], workspace, wbytes, *dims, dv, dl, flags, None, None,
     )
 
 
@@ -98,7 +98,7 @@ def test_backward_argument_errors():
     assert _bwd(grad_attn=None) == -1
     assert _bwd(dims=(2, 64, 2, 32, 64, 0, 2)) == -2
     assert _bwd(dv=5) == -3
-    need = _lib.load().msda_backward_workspace_bytes(2, 64, 2, 32, 64, 1, 2, 2, 2, 0)
+    need = _lib.load().msda_backward_workspace_bytes(2, 64, 2, 32, 64, 1, 2, 2, 2, 0, None)
     assert need > 0
     assert _bwd(workspace=None, wbytes=0) == -5
     assert _bwd(workspace=FAKE * 16, wbytes=need - 1) == -5
@@ -106,7 +106,11 @@ def test_backward_argument_errors():
 
 
 def test_workspace_bytes():
-    ws = _lib.load().msda_backward_workspace_bytes
+    ws_h = _lib.load().msda_backward_workspace_bytes
+
+    def ws(*a):
+        return ws_h(*a, None)
+
     # generic fp32 / fp64 paths accumulate straight into grad_value
     assert ws(1, 640, 2, 30, 2, 2, 2, _lib.F32, _lib.F32, 0) == 0
     assert ws(1, 640, 2, 30, 2, 2, 2, _lib.F64, _lib.F64, 0) == 0
@@ -126,6 +130,20 @@ def test_workspace_bytes():
     assert ws(n, s, m, d, s, l, p, _lib.BF16, _lib.F32, _lib.FLAG_ATOMIC_SCATTER) == n * s * m * d * 4
     # invalid arguments give 0
     assert ws(0, s, m, d, s, l, p, _lib.F32, _lib.F32, 0) == 0
+    # host level shapes select 16x16 patches: same count here (every extent divides by 16) ...
+    host = (ctypes.c_int64 * 6)(128, 256, 64, 128, 32, 64)
+    assert ws_h(n, s, m, d, s, l, p, _lib.F32, _lib.F32, 0, host) == ws(n, s, m, d, s, l, p, _lib.F32, _lib.F32, 0)
+    # ... more tiles when the extents are ragged (3 levels of 20x24, 10x12, 5x6: 4+1+1 patches
+    # against ceil(630/256) = 3 runs), and the 1-D plan when the table does not cover S
+    s2 = 20 * 24 + 10 * 12 + 5 * 6
+    ragged = (ctypes.c_int64 * 6)(20, 24, 10, 12, 5, 6)
+    base = ws(1, s2, m, d, s2, l, p, _lib.F32, _lib.F32, 0)
+    qb2 = -(-s2 // 256)
+    r256 = lambda x: -(-x // 256) * 256
+    assert (ws_h(1, s2, m, d, s2, l, p, _lib.F32, _lib.F32, 0, ragged) - base
+            == r256(m * qb2 * 6 * 8) - r256(m * qb2 * 3 * 8))
+    wrong = (ctypes.c_int64 * 6)(20, 24, 10, 12, 5, 7)
+    assert ws_h(1, s2, m, d, s2, l, p, _lib.F32, _lib.F32, 0, wrong) == base
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):

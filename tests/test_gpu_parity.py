@@ -144,6 +144,26 @@ def test_fp16_generic_and_tuned():
         assert np.abs(g - w_).max() / (np.abs(w_).max() + 1e-30) <= 2**-9
 
 
+@pytest.mark.parametrize("case", ["enc_L3P4", "heads3_d64", "d16_ragged"])
+def test_scatter_tile_geometries_agree(case, monkeypatch):
+    """With the level shapes known on the host the binned scatter cuts grad_value into 2-D
+    patches, without them into runs of the flattened sequence: same result, both within the
+    oracle tolerance."""
+    n, m, d, lq, levels, p = MID[case]
+    value, shapes, lsi, loc, attn, grad_out = make_inputs(
+        n, m, d, lq, levels, p, dtype=torch.float32, seed=17, device="cuda"
+    )
+    want = _oracle64(value, shapes, loc, attn, grad_out)
+    bwd = torch.ops.unipercept.ms_deform_attn_bwd
+    patches = bwd(grad_out, value, shapes, lsi, loc, attn, 0)
+    monkeypatch.setenv("MSDA_SKIP_LEVEL_CHECK", "1")  # no host copy of the table -> 1-D runs
+    runs = bwd(grad_out, value, shapes, lsi, loc, attn, 0)
+    for a, b, w_ in zip(patches, runs, want[1:]):
+        assert (a - b).abs().max() <= 1e-5
+        assert np.abs(a.cpu().double().numpy() - w_).max() <= BWD_ATOL_F32
+        assert np.abs(b.cpu().double().numpy() - w_).max() <= BWD_ATOL_F32
+
+
 def test_head_major_layout_matches_position_major(monkeypatch):
     """The per-head value copy is a pure re-layout: identical results either way."""
     from unipercept_amd import _lib

@@ -42,13 +42,16 @@ def test_shape_and_dtype_validation(mutate, exc):
 def test_level_table_check():
     shapes = torch.tensor([[4, 4], [2, 2]])
     lsi = level_start_index(shapes)
-    _ops._check_levels(shapes, lsi, 20)
+    host = _ops._check_levels(shapes, lsi, shapes, lsi, 20)
+    assert list(host) == [4, 4, 2, 2]  # host copy of the (H, W) pairs, handed to the backward
     with pytest.raises(ValueError, match="cover"):
-        _ops._check_levels(shapes.clone(), lsi.clone(), 21)
+        _ops._check_levels(shapes, lsi, shapes, lsi, 21)
+    bad = torch.tensor([0, 15])
     with pytest.raises(ValueError, match="prefix sum"):
-        _ops._check_levels(shapes.clone(), torch.tensor([0, 15]), 20)
+        _ops._check_levels(shapes, bad, shapes, bad, 20)
+    zero, z = torch.tensor([[4, 0], [2, 2]]), torch.tensor([0, 0])
     with pytest.raises(ValueError, match="positive"):
-        _ops._check_levels(torch.tensor([[4, 0], [2, 2]]), torch.tensor([0, 0]), 4)
+        _ops._check_levels(zero, z, zero, z, 4)
 
 
 def test_im2col_step_is_validated_before_any_launch():

@@ -10,7 +10,7 @@ from pathlib import Path
 _PKG = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ.get("MSDA_LIBRARY", _PKG / "libmsda.so"))
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 # dtype codes of include/msda.h
 F32, F64, BF16, F16 = 0, 1, 2, 3
@@ -54,9 +54,11 @@ def _declare(lib: ctypes.CDLL) -> None:
     lib.msda_value_relayout.restype = c_int
     lib.msda_value_relayout.argtypes = [c_vp, c_vp] + [c_int] * 6 + [c_vp]
     lib.msda_backward_workspace_bytes.restype = c_sz
-    lib.msda_backward_workspace_bytes.argtypes = [c_int] * 7 + [c_int, c_int, c_int]
+    lib.msda_backward_workspace_bytes.argtypes = [c_int] * 7 + [c_int, c_int, c_int, c_vp]
     lib.msda_backward.restype = c_int
-    lib.msda_backward.argtypes = [c_vp] * 10 + [c_sz] + [c_int] * 7 + [c_int, c_int, c_int, c_vp]
+    lib.msda_backward.argtypes = (
+        [c_vp] * 10 + [c_sz] + [c_int] * 7 + [c_int, c_int, c_int, c_vp, c_vp]
+    )
 
 
 def load() -> ctypes.CDLL:

@@ -10,7 +10,7 @@ namespace {
 
 using namespace msda;
 
-constexpr int kAbiVersion = 1;
+constexpr int kAbiVersion = 2;
 
 inline size_t elem_size(int dtype) {
   switch (dtype) {
@@ -226,12 +226,14 @@ int msda_value_relayout(const void* src, void* dst, int N, int S, int M, int D, 
 }
 
 size_t msda_backward_workspace_bytes(int N, int S, int M, int D, int Lq, int L, int P,
-                                     int dtype_val, int dtype_loc, int flags) {
+                                     int dtype_val, int dtype_loc, int flags,
+                                     const int64_t* shapes_host) {
   if (check_common(N, S, M, D, Lq, L, P, dtype_val, dtype_loc) != MSDA_OK) return 0;
   if (flags & MSDA_FLAG_DETERMINISTIC) return 0;
   if (!(flags & MSDA_FLAG_GENERIC)) {
     const int64_t t = tuned_backward_workspace_bytes(N, S, M, D, Lq, L, P, dtype_val, dtype_loc,
-                                                     !(flags & MSDA_FLAG_ATOMIC_SCATTER));
+                                                     !(flags & MSDA_FLAG_ATOMIC_SCATTER),
+                                                     shapes_host);
     if (t >= 0) return static_cast<size_t>(t);
   }
   if (needs_f32_image(dtype_val)) return static_cast<size_t>(N) * S * M * D * sizeof(float);
@@ -242,7 +244,7 @@ int msda_backward(const void* grad_out, const void* value, const int64_t* shapes
                   const int64_t* lsi_dev, const void* loc, const void* attn, void* grad_value,
                   void* grad_loc, void* grad_attn, void* workspace, size_t workspace_bytes, int N,
                   int S, int M, int D, int Lq, int L, int P, int dtype_val, int dtype_loc,
-                  int flags, void* hip_stream) {
+                  int flags, const int64_t* shapes_host, void* hip_stream) {
   if (!grad_out || !value || !shapes_dev || !lsi_dev || !loc || !attn || !grad_value ||
       !grad_loc || !grad_attn)
     return MSDA_ENULL;
@@ -254,7 +256,8 @@ int msda_backward(const void* grad_out, const void* value, const int64_t* shapes
       !aligned(grad_attn, el) || !aligned(shapes_dev, 8) || !aligned(lsi_dev, 8))
     return MSDA_EALIGN;
   const size_t need =
-      msda_backward_workspace_bytes(N, S, M, D, Lq, L, P, dtype_val, dtype_loc, flags);
+      msda_backward_workspace_bytes(N, S, M, D, Lq, L, P, dtype_val, dtype_loc, flags,
+                                    shapes_host);
   if (need > 0 && (!workspace || workspace_bytes < need || !aligned(workspace, 256)))
     return MSDA_EWORKSPACE;
   const Dims d{N, S, M, D, Lq, L, P};
@@ -265,7 +268,7 @@ int msda_backward(const void* grad_out, const void* value, const int64_t* shapes
     const int t = tuned_backward(grad_out, value, shapes_dev, lsi_dev, loc, attn, grad_value,
                                  grad_loc, grad_attn, workspace, N, S, M, D, Lq, L, P, dtype_val,
                                  dtype_loc, !(flags & MSDA_FLAG_ATOMIC_SCATTER),
-                                 (flags & MSDA_FLAG_VALUE_HEAD_MAJOR) != 0, stream);
+                                 (flags & MSDA_FLAG_VALUE_HEAD_MAJOR) != 0, shapes_host, stream);
     if (t != kNotTuned) return t;
   }
   if (flags & MSDA_FLAG_VALUE_HEAD_MAJOR) return MSDA_ELAYOUT;

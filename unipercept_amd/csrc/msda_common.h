@@ -64,6 +64,8 @@ struct Footprint {
   CT dwx[4];    // d w / d x   (0 for a corner outside the level)
   CT dwy[4];    // d w / d y
   int pix[4];   // y*W + x of the corner, clamped into the level (valid address even when w == 0)
+  int cy[2];    // clamped rows y0, y0+1    (corner k sits at row cy[k >> 1], column cx[k & 1])
+  int cx[2];    // clamped columns x0, x0+1
   bool valid[4];  // corner lies inside the level (and the point inside the skirt)
   bool any;     // false when the point lies outside the (-1, H) x (-1, W) skirt: contributes nothing
 };
@@ -90,6 +92,10 @@ __device__ __forceinline__ Footprint<CT> footprint(CT locx, CT locy, int H, int 
   const CT w[4] = {hy * hx, hy * lx, ly * hx, ly * lx};
   const CT dx[4] = {-hy, hy, -ly, ly};
   const CT dy[4] = {-hx, -lx, hx, lx};
+  f.cy[0] = yc0;
+  f.cy[1] = yc1;
+  f.cx[0] = xc0;
+  f.cx[1] = xc1;
   f.pix[0] = yc0 * W + xc0;
   f.pix[1] = yc0 * W + xc1;
   f.pix[2] = yc1 * W + xc0;

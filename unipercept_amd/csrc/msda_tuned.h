@@ -117,18 +117,79 @@ __host__ __device__ constexpr int group_stride_slots(int LP, int slots) { return
 //   x = query index | level << 28, y = attention weight, z/w = normalised location (x, y) as f32
 constexpr uint32_t kRecInvalid = 0xffffffffu;
 
-// Distinct destination tiles of a footprint (at most 4), written to t0..t3; returns the count.
-__device__ __forceinline__ int footprint_tiles(const Footprint<float>& f, int start, int ts_shift,
+// positions per destination tile, by head dim
+#ifndef MSDA_TS_SMALL_D
+#define MSDA_TS_SMALL_D 256
+#endif
+__host__ __device__ constexpr int tile_positions(int D) { return D <= 32 ? MSDA_TS_SMALL_D : 128; }
+
+// Destination tiles of the binned grad_value scatter.  tile2d = 0: a tile is TS consecutive
+// positions of the flattened (level-concatenated) sequence.  tile2d = 1: a tile is a
+// (TS/16) x 16 pixel patch of one level — a bilinear footprint then straddles two tiles only
+// near patch edges (1.13 records per point instead of 1.58 on the Cityscapes pyramid); the tile
+// count needs the level shapes on the host.
+struct BinPlan {
+  int ts_shift;     // log2 of the tile size in positions
+  int n_tiles;      // tiles per (batch, head) slab
+  int qb;           // queries per query-side workgroup
+  int n_qblocks;    // ceil(Lq / qb)
+  uint32_t region;  // records per workgroup region
+  int tile2d;       // tile geometry (see above)
+  int ablate;       // diagnostic runs only: bit mask of phases to skip (results are then wrong)
+};
+
+struct TileMap {  // tile2d only: first tile id and tiles per row of every level
+  int tstart[kMaxLevelsTuned + 1];
+  int tx[kMaxLevelsTuned];
+};
+
+__device__ __forceinline__ void build_tile_map(const LevelInfo* lv, int L, int ts_shift, TileMap& tm) {
+  const int th_shift = ts_shift - 4;
+  int run = 0;
+  for (int l = 0; l < L; ++l) {
+    const int tx = (lv[l].W + 15) >> 4;
+    const int ty = (lv[l].H + (1 << th_shift) - 1) >> th_shift;
+    tm.tstart[l] = run;
+    tm.tx[l] = tx;
+    run += tx * ty;
+  }
+  tm.tstart[L] = run;
+}
+
+// tile id and position inside the tile of the pixel (cy, cx) of level l
+__device__ __forceinline__ void pixel_tile(const BinPlan& plan, const TileMap& tm,
+                                           const LevelInfo& L_, int l, int cy, int cx,
+                                           uint32_t& tile, uint32_t& local) {
+  if (plan.tile2d) {
+    const int th_shift = plan.ts_shift - 4;
+    tile = static_cast<uint32_t>(tm.tstart[l] + (cy >> th_shift) * tm.tx[l] + (cx >> 4));
+    local = static_cast<uint32_t>(((cy & ((1 << th_shift) - 1)) << 4) | (cx & 15));
+  } else {
+    const uint32_t pos = static_cast<uint32_t>(L_.start + cy * L_.W + cx);
+    tile = pos >> plan.ts_shift;
+    local = pos & ((1u << plan.ts_shift) - 1u);
+  }
+}
+
+// Distinct destination tiles of a footprint (at most 4), compacted into tiles[]; returns the
+// count.  Tiles at or beyond plan.n_tiles (host and device level tables disagree) are dropped.
+__device__ __forceinline__ int footprint_tiles(const Footprint<float>& f, const BinPlan& plan,
+                                               const TileMap& tm, const LevelInfo& L_, int l,
                                                uint32_t (&tiles)[4]) {
   uint32_t t[4];
+  bool ok[4];
 #pragma unroll
-  for (int k = 0; k < 4; ++k) t[k] = static_cast<uint32_t>(start + f.pix[k]) >> ts_shift;
-  // keep corner k when it is valid and no earlier valid corner has the same tile
-  const bool keep0 = f.valid[0];
-  const bool keep1 = f.valid[1] && !(f.valid[0] && t[0] == t[1]);
-  const bool keep2 = f.valid[2] && !(f.valid[0] && t[0] == t[2]) && !(f.valid[1] && t[1] == t[2]);
-  const bool keep3 = f.valid[3] && !(f.valid[0] && t[0] == t[3]) && !(f.valid[1] && t[1] == t[3]) &&
-                     !(f.valid[2] && t[2] == t[3]);
+  for (int k = 0; k < 4; ++k) {
+    uint32_t local;
+    pixel_tile(plan, tm, L_, l, f.cy[k >> 1], f.cx[k & 1], t[k], local);
+    ok[k] = f.valid[k] && t[k] < static_cast<uint32_t>(plan.n_tiles);
+  }
+  // keep corner k when it counts and no earlier counting corner has the same tile
+  const bool keep0 = ok[0];
+  const bool keep1 = ok[1] && !(ok[0] && t[0] == t[1]);
+  const bool keep2 = ok[2] && !(ok[0] && t[0] == t[2]) && !(ok[1] && t[1] == t[2]);
+  const bool keep3 = ok[3] && !(ok[0] && t[0] == t[3]) && !(ok[1] && t[1] == t[3]) &&
+                     !(ok[2] && t[2] == t[3]);
   const bool keep[4] = {keep0, keep1, keep2, keep3};
   int n = 0;
 #pragma unroll
@@ -146,7 +207,8 @@ struct EmitCtx {
   uint4* records;      // this workgroup's record region
   uint32_t* tile_off;  // LDS: exclusive prefix of records per tile inside the region
   uint32_t* tile_cnt;  // LDS: running rank per tile
-  int ts_shift;
+  const BinPlan* plan;
+  const TileMap* tm;
 };
 
 // Stages the points of `nq` consecutive queries of head m (first query q_first) into LDS.
@@ -192,7 +254,7 @@ __device__ __forceinline__ void stage_chunk(const LevelInfo* lv, const LT* __res
     if constexpr (EMIT) {
       if (f.any && a != 0.f && emit.records != nullptr) {
         uint32_t tiles[4] = {0, 0, 0, 0};
-        const int n = footprint_tiles(f, L_.start, emit.ts_shift, tiles);
+        const int n = footprint_tiles(f, *emit.plan, *emit.tm, L_, l, tiles);
         uint4 rec;
         rec.x = static_cast<uint32_t>(q_first + g) | (static_cast<uint32_t>(l) << 28);
         rec.y = __float_as_uint(a);
@@ -321,20 +383,6 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t* data, int n, 
   return total;
 }
 
-// positions per destination tile, by head dim
-#ifndef MSDA_TS_SMALL_D
-#define MSDA_TS_SMALL_D 256
-#endif
-__host__ __device__ constexpr int tile_positions(int D) { return D <= 32 ? MSDA_TS_SMALL_D : 128; }
-
-struct BinPlan {
-  int ts_shift;     // log2 of the tile size in positions
-  int n_tiles;      // ceil(S / TS)
-  int qb;           // queries per query-side workgroup
-  int n_qblocks;    // ceil(Lq / qb)
-  uint32_t region;  // records per workgroup region
-  int ablate;       // diagnostic runs only: bit mask of phases to skip (results are then wrong)
-};
 
 // MODE 0: grad_loc / grad_attn + grad_value by global fp32 atomics into `gv_acc`
 // MODE 1: grad_loc / grad_attn + scatter records for the tile kernel
@@ -351,6 +399,7 @@ __global__ __launch_bounds__(256) void bwd_query_kernel(
   constexpr int GPB = 256 / G;
   extern __shared__ uint4 lds[];
   __shared__ LevelInfo lv[kMaxLevelsTuned];
+  __shared__ TileMap tm;
   __shared__ uint32_t scan_tmp[256];
 
   const int LP = L * P;
@@ -361,6 +410,10 @@ __global__ __launch_bounds__(256) void bwd_query_kernel(
   const int qb_n = min(plan.qb, Lq - qb0);
   if (threadIdx.x < L) lv[threadIdx.x] = load_level(shapes, lsi, threadIdx.x, S);
   __syncthreads();
+  if (MODE == 1 && plan.tile2d) {
+    if (threadIdx.x == 0) build_tile_map(lv, L, plan.ts_shift, tm);
+    __syncthreads();
+  }
 
   const uint32_t rowb = static_cast<uint32_t>(head_major ? 1 : M) * D * sizeof(VT);
   const uint32_t headb = static_cast<uint32_t>(m) * (head_major ? S : 1) * D * sizeof(VT);
@@ -385,7 +438,7 @@ __global__ __launch_bounds__(256) void bwd_query_kernel(
       const Footprint<float> f = footprint<float>(x, y, L_.H, L_.W);
       if (f.any && a != 0.f) {
         uint32_t tiles[4] = {0, 0, 0, 0};
-        const int n = footprint_tiles(f, L_.start, plan.ts_shift, tiles);
+        const int n = footprint_tiles(f, plan, tm, L_, l, tiles);
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           if (j < n) atomicAdd(&tile_cnt[tiles[j]], 1u);
@@ -405,7 +458,8 @@ __global__ __launch_bounds__(256) void bwd_query_kernel(
     emit.records = records + (slab * plan.n_qblocks + qblock) * static_cast<int64_t>(plan.region);
     emit.tile_off = tile_off;
     emit.tile_cnt = tile_cnt;
-    emit.ts_shift = plan.ts_shift;
+    emit.plan = &plan;
+    emit.tm = &tm;
     __syncthreads();
   }
 
@@ -552,7 +606,9 @@ __global__ __launch_bounds__(256) void bwd_tile_kernel(
   constexpr int PPG = TS / PG;                // positions owned by one entry group
   extern __shared__ uint4 lds[];
   __shared__ LevelInfo lv[kMaxLevelsTuned];
+  __shared__ TileMap tm;
   __shared__ uint32_t n_runs_s, total_s;
+  __shared__ int tile_level_s, tile_y0_s, tile_x0_s;  // tile2d: the patch this workgroup owns
 
   char* gstage = reinterpret_cast<char*>(lds);                                // R rows
   uint2* entries = reinterpret_cast<uint2*>(gstage + R * ROWB);               // 4 * R
@@ -573,6 +629,18 @@ __global__ __launch_bounds__(256) void bwd_tile_kernel(
   }
   for (int i = threadIdx.x; i < TS; i += 256) cnt[i] = 0;
   __syncthreads();
+  if (plan.tile2d && threadIdx.x == 0) {
+    build_tile_map(lv, L, plan.ts_shift, tm);
+    int l = -1;
+    for (int k = 0; k < L; ++k)
+      if (tile >= tm.tstart[k] && tile < tm.tstart[k + 1]) l = k;
+    tile_level_s = l;
+    if (l >= 0) {
+      const int r = tile - tm.tstart[l];
+      tile_y0_s = (r / tm.tx[l]) << (plan.ts_shift - 4);
+      tile_x0_s = (r % tm.tx[l]) << 4;
+    }
+  }
   // the non-empty runs of this tile: (record count, first record index inside the slab)
   for (int qbk = threadIdx.x; qbk < plan.n_qblocks; qbk += 256) {
     const uint2 e = dir[(slab * plan.n_qblocks + qbk) * plan.n_tiles + tile];
@@ -635,15 +703,16 @@ __global__ __launch_bounds__(256) void bwd_tile_kernel(
     float loc_w[4];
     bool in_tile[4] = {false, false, false, false};
     if (have) {
-      const LevelInfo L_ = lv[rec.x >> 28];
+      const int l = static_cast<int>(rec.x >> 28);
+      const LevelInfo L_ = lv[l];
       const float a = __uint_as_float(rec.y);
       const Footprint<float> f =
           footprint<float>(__uint_as_float(rec.z), __uint_as_float(rec.w), L_.H, L_.W);
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const uint32_t pos = static_cast<uint32_t>(L_.start + f.pix[k]);
-        in_tile[k] = f.valid[k] && (pos >> plan.ts_shift) == tile_u;
-        loc_pix[k] = pos & (TS - 1);
+        uint32_t t;
+        pixel_tile(plan, tm, L_, l, f.cy[k >> 1], f.cx[k & 1], t, loc_pix[k]);
+        in_tile[k] = f.valid[k] && t == tile_u;
         loc_w[k] = a * f.w[k];
         if (in_tile[k]) atomicAdd(&cnt[loc_pix[k]], 1u);
       }
@@ -716,8 +785,18 @@ __global__ __launch_bounds__(256) void bwd_tile_kernel(
   const int64_t row_elems = static_cast<int64_t>(M) * D;
 #pragma unroll
   for (int p = 0; p < PPG; ++p) {
-    const int64_t pos = static_cast<int64_t>(tile) * TS + pg * PPG + p;
-    if (pos >= S) break;
+    int64_t pos;
+    if (plan.tile2d) {
+      const int l = tile_level_s;
+      if (l < 0) break;
+      const int local = pg * PPG + p;
+      const int yy = tile_y0_s + (local >> 4), xx = tile_x0_s + (local & 15);
+      if (yy >= lv[l].H || xx >= lv[l].W) continue;
+      pos = lv[l].start + static_cast<int64_t>(yy) * lv[l].W + xx;
+    } else {
+      pos = static_cast<int64_t>(tile) * TS + pg * PPG + p;
+    }
+    if (pos >= S) continue;
     char* dst = reinterpret_cast<char*>(grad_value) +
                 (((static_cast<int64_t>(b) * S + pos) * row_elems) + m * D) * sizeof(VT);
     if constexpr (CPR == 2) {
@@ -783,28 +862,53 @@ inline bool all_aligned16(std::initializer_list<const void*> ps) {
 }
 
 // Binned grad_value plan; returns false when the shape is outside what the binned path handles
-// (very long sequences), in which case the fp32-atomic query kernel is used.
-inline bool make_bin_plan(int N, int S, int M, int D, int Lq, int L, int P, BinPlan* plan,
-                          size_t* dir_bytes, size_t* rec_bytes) {
+// (very long sequences), in which case the fp32-atomic query kernel is used.  `levels_host`
+// (L pairs (H, W), host memory, may be null) selects the 2-D tile geometry when the level table
+// is a plain pyramid (positive extents that sum to S) and its tile count is within the limits;
+// otherwise tiles are runs of the flattened sequence.
+inline bool make_bin_plan(int N, int S, int M, int D, int Lq, int L, int P,
+                          const int64_t* levels_host, BinPlan* plan, size_t* dir_bytes,
+                          size_t* rec_bytes) {
   if (D > 64) return false;                  // the LDS row stage of a slice is 256 * D * 4 B
   const int ts_shift = tile_positions(D) == 512 ? 9 : tile_positions(D) == 256 ? 8 : 7;
   const int TS = 1 << ts_shift;
-  const int64_t n_tiles = (static_cast<int64_t>(S) + TS - 1) / TS;
   const int qb = 256;
   const int64_t n_qblocks = (static_cast<int64_t>(Lq) + qb - 1) / qb;
-  if (n_tiles > 2048 || n_qblocks > 2048 || Lq >= (1 << 28)) return false;
   const int64_t slabs = static_cast<int64_t>(N) * M;
+  const auto fits = [&](int64_t nt) {
+    return nt <= 2048 && slabs * n_qblocks * nt * 8 <= (static_cast<int64_t>(1) << 30) &&
+           nt * M <= INT32_MAX;
+  };
+  int64_t n_tiles = (static_cast<int64_t>(S) + TS - 1) / TS;
+  int tile2d = 0;
+  if (levels_host != nullptr && getenv("MSDA_EXP_TILE1D") == nullptr) {
+    const int th = TS / 16;
+    int64_t total = 0, nt = 0;
+    bool ok = true;
+    for (int l = 0; l < L; ++l) {
+      const int64_t h = levels_host[2 * l], w = levels_host[2 * l + 1];
+      if (h < 1 || w < 1 || h > S || w > S) { ok = false; break; }
+      total += h * w;
+      nt += ((h + th - 1) / th) * ((w + 15) / 16);
+      if (total > S) { ok = false; break; }
+    }
+    if (ok && total == S && fits(nt)) {
+      n_tiles = nt;
+      tile2d = 1;
+    }
+  }
+  if (!fits(n_tiles) || n_qblocks > 2048 || Lq >= (1 << 28)) return false;
   const int64_t dir_b = slabs * n_qblocks * n_tiles * 8;
-  if (dir_b > (static_cast<int64_t>(1) << 30)) return false;
   // a point lands in at most 4 tiles: regions can never overflow
   const int64_t region = static_cast<int64_t>(qb) * L * P * 4;
   const int64_t rec_b = slabs * n_qblocks * region * 16;
-  if (n_tiles * M > INT32_MAX || n_qblocks * M > INT32_MAX) return false;
+  if (n_qblocks * M > INT32_MAX) return false;
   plan->ts_shift = ts_shift;
   plan->n_tiles = static_cast<int>(n_tiles);
   plan->qb = qb;
   plan->n_qblocks = static_cast<int>(n_qblocks);
   plan->region = static_cast<uint32_t>(region);
+  plan->tile2d = tile2d;
   plan->ablate = getenv("MSDA_EXP_ABLATE") ? atoi(getenv("MSDA_EXP_ABLATE")) : 0;
   *dir_bytes = (static_cast<size_t>(dir_b) + 255) & ~static_cast<size_t>(255);
   *rec_bytes = static_cast<size_t>(rec_b);
@@ -819,7 +923,7 @@ inline bool head_major_supported(int N, int S, int M, int D, int Lq, int L, int 
   BinPlan plan;
   size_t a, b;
   return tuned_shape_ok(N, S, M, D, Lq, L, P, dtype_val, dtype_loc, &G) &&
-         make_bin_plan(N, S, M, D, Lq, L, P, &plan, &a, &b);
+         make_bin_plan(N, S, M, D, Lq, L, P, nullptr, &plan, &a, &b);
 }
 
 // (N,S,M,D) <-> (N,M,S,D): rows of D*e bytes move whole, 16 bytes per lane
@@ -880,12 +984,13 @@ inline int tuned_forward(const void* value, const int64_t* shapes, const int64_t
 }
 
 inline int64_t tuned_backward_workspace_bytes(int N, int S, int M, int D, int Lq, int L, int P,
-                                              int dtype_val, int dtype_loc, bool allow_binned) {
+                                              int dtype_val, int dtype_loc, bool allow_binned,
+                                              const int64_t* levels_host) {
   int G;
   if (!tuned_shape_ok(N, S, M, D, Lq, L, P, dtype_val, dtype_loc, &G)) return -1;
   BinPlan plan;
   size_t dir_b, rec_b;
-  if (allow_binned && make_bin_plan(N, S, M, D, Lq, L, P, &plan, &dir_b, &rec_b))
+  if (allow_binned && make_bin_plan(N, S, M, D, Lq, L, P, levels_host, &plan, &dir_b, &rec_b))
     return static_cast<int64_t>(dir_b + rec_b);
   if (dtype_val == 0) return 0;
   return static_cast<int64_t>(N) * S * M * D * 4;  // fp32 accumulation image of grad_value
@@ -896,13 +1001,14 @@ int tuned_backward_typed(const void* grad_out, const void* value, const int64_t*
                          const int64_t* lsi, const void* loc, const void* attn, void* grad_value,
                          void* grad_loc, void* grad_attn, void* workspace, int N, int S, int M,
                          int D, int Lq, int L, int P, int G, bool allow_binned, bool head_major,
-                         hipStream_t stream) {
+                         const int64_t* levels_host, hipStream_t stream) {
   const int GPB = 256 / G;
   const int LP = L * P;
   const int LPB = stage_points_per_pass(G, LP);
   BinPlan plan{};
   size_t dir_b = 0, rec_b = 0;
-  const bool binned = allow_binned && make_bin_plan(N, S, M, D, Lq, L, P, &plan, &dir_b, &rec_b);
+  const bool binned =
+      allow_binned && make_bin_plan(N, S, M, D, Lq, L, P, levels_host, &plan, &dir_b, &rec_b);
   hipError_t e;
 
   if (binned) {
@@ -941,6 +1047,7 @@ int tuned_backward_typed(const void* grad_out, const void* value, const int64_t*
   plan.qb = 256;
   plan.n_qblocks = (Lq + plan.qb - 1) / plan.qb;
   plan.n_tiles = 0;
+  plan.tile2d = 0;
   plan.ablate = 0;
   const dim3 grid(static_cast<unsigned>(plan.n_qblocks) * M, N);
   const size_t lds = static_cast<size_t>(GPB) * group_stride_slots(LPB, 3) * 16;
@@ -980,13 +1087,14 @@ inline int tuned_backward(const void* grad_out, const void* value, const int64_t
                           const int64_t* lsi, const void* loc, const void* attn, void* grad_value,
                           void* grad_loc, void* grad_attn, void* workspace, int N, int S, int M,
                           int D, int Lq, int L, int P, int dtype_val, int dtype_loc,
-                          bool allow_binned, bool head_major, hipStream_t stream) {
+                          bool allow_binned, bool head_major, const int64_t* levels_host,
+                          hipStream_t stream) {
   int G;
   if (!tuned_shape_ok(N, S, M, D, Lq, L, P, dtype_val, dtype_loc, &G)) return kNotTuned;
   if (!all_aligned16({value, grad_out, grad_value, workspace})) return kNotTuned;
 #define MSDA_ARGS                                                                               \
   grad_out, value, shapes, lsi, loc, attn, grad_value, grad_loc, grad_attn, workspace, N, S, M, \
-      D, Lq, L, P, G, allow_binned, head_major, stream
+      D, Lq, L, P, G, allow_binned, head_major, levels_host, stream
   if (dtype_val == 0) return tuned_backward_typed<float, float>(MSDA_ARGS);
   if (dtype_val == 2)
     return dtype_loc == 0 ? tuned_backward_typed<bf16_t, float>(MSDA_ARGS)

@@ -8,6 +8,7 @@ through ``libmsda.so``; there is no CPU implementation.
 
 from __future__ import annotations
 
+import ctypes
 import os
 
 import torch
@@ -21,6 +22,8 @@ _DTYPE_CODE = {
     torch.float16: _lib.F16,
 }
 
+# device level tables already checked: key -> (shapes tensor, lsi tensor, host copy).  The
+# tensors are kept alive so that their addresses cannot be recycled while the entry exists.
 _level_cache: dict[tuple, tuple] = {}
 
 
@@ -33,17 +36,7 @@ def _dims(value, loc, head_major: bool = False):
     return n, s, m, d, lq, l, p
 
 
-def _check_levels(shapes: torch.Tensor, lsi: torch.Tensor, s: int) -> None:
-    """Host-side consistency check of the level table (cached: it costs one device sync)."""
-    if os.environ.get("MSDA_SKIP_LEVEL_CHECK") == "1":
-        return
-    key = (shapes.data_ptr(), shapes._version, lsi.data_ptr(), lsi._version, s, shapes.device)
-    if key in _level_cache:
-        return
-    if shapes.is_cuda and torch.cuda.is_current_stream_capturing():
-        return  # cannot synchronise while a graph is being captured; the kernels guard themselves
-    hw = shapes.tolist()
-    st = lsi.tolist()
+def _checked_host_levels(hw, st, s: int):
     run = 0
     for (h, w), start in zip(hw, st):
         if h < 1 or w < 1:
@@ -55,9 +48,30 @@ def _check_levels(shapes: torch.Tensor, lsi: torch.Tensor, s: int) -> None:
         run += h * w
     if run != s:
         raise ValueError(f"value has {s} positions but spatial_shapes {hw} cover {run}")
+    flat = [int(x) for pair in hw for x in pair]
+    return (ctypes.c_int64 * len(flat))(*flat)
+
+
+def _check_levels(shapes_in, lsi_in, shapes: torch.Tensor, lsi: torch.Tensor, s: int):
+    """Host-side consistency check of the level table.  Returns a host copy of the (H, W) pairs
+    (a ctypes int64 array; the backward sizes its 2-D scatter tiles from it) or None when the
+    table cannot be read without a forbidden sync.  A table handed in on the host is read
+    directly; a device table costs one sync the first time and is cached afterwards."""
+    if os.environ.get("MSDA_SKIP_LEVEL_CHECK") == "1":
+        return None
+    if shapes_in.device.type == "cpu" and lsi_in.device.type == "cpu":
+        return _checked_host_levels(shapes_in.tolist(), lsi_in.tolist(), s)
+    key = (shapes.data_ptr(), shapes._version, lsi.data_ptr(), lsi._version, s, shapes.device)
+    hit = _level_cache.get(key)
+    if hit is not None:
+        return hit[2]
+    if shapes.is_cuda and torch.cuda.is_current_stream_capturing():
+        return None  # cannot synchronise while a graph is being captured; the kernels guard themselves
+    host = _checked_host_levels(shapes.tolist(), lsi.tolist(), s)
     if len(_level_cache) > 256:
         _level_cache.clear()
-    _level_cache[key] = (hw, st)
+    _level_cache[key] = (shapes, lsi, host)
+    return host
 
 
 def _validate(value, shapes, lsi, loc, attn, head_major: bool = False):
@@ -90,9 +104,11 @@ def _validate(value, shapes, lsi, loc, attn, head_major: bool = False):
 
 
 def _prepare(value, shapes, lsi, loc, attn, head_major: bool = False):
-    """Returns contiguous, dtype-consistent tensors on value's device."""
+    """Returns contiguous, dtype-consistent tensors on value's device and the host copy of the
+    level shapes (or None)."""
     _validate(value, shapes, lsi, loc, attn, head_major)
     dev = value.device
+    shapes_in, lsi_in = shapes, lsi
     shapes = shapes.to(device=dev, dtype=torch.int64).contiguous()
     lsi = lsi.to(device=dev, dtype=torch.int64).contiguous()
     vdt = value.dtype
@@ -104,8 +120,8 @@ def _prepare(value, shapes, lsi, loc, attn, head_major: bool = False):
     loc = loc.to(ldt).contiguous()
     attn = attn.to(ldt).contiguous()
     value = value.contiguous()
-    _check_levels(shapes, lsi, value.shape[2 if head_major else 1])
-    return value, shapes, lsi, loc, attn
+    levels_host = _check_levels(shapes_in, lsi_in, shapes, lsi, value.shape[2 if head_major else 1])
+    return value, shapes, lsi, loc, attn, levels_host
 
 
 def _stream_ptr(device) -> int:
@@ -123,7 +139,7 @@ def ms_deform_attn_fwd(
 ) -> torch.Tensor:
     lib = _lib.load()
     hm = bool(flags & _lib.FLAG_VALUE_HEAD_MAJOR)
-    value, shapes, lsi, loc, attn = _prepare(
+    value, shapes, lsi, loc, attn, _ = _prepare(
         value, spatial_shapes, level_start_index, sampling_locations, attention_weights, hm
     )
     n, s, m, d, lq, l, p = _dims(value, loc, hm)
@@ -158,7 +174,7 @@ def ms_deform_attn_bwd(
     lib = _lib.load()
     loc_dtype, attn_dtype = sampling_locations.dtype, attention_weights.dtype
     hm = bool(flags & _lib.FLAG_VALUE_HEAD_MAJOR)
-    value, shapes, lsi, loc, attn = _prepare(
+    value, shapes, lsi, loc, attn, levels_host = _prepare(
         value, spatial_shapes, level_start_index, sampling_locations, attention_weights, hm
     )
     n, s, m, d, lq, l, p = _dims(value, loc, hm)
@@ -170,7 +186,9 @@ def ms_deform_attn_bwd(
     grad_attn = torch.empty_like(attn)
     vcode, lcode = _DTYPE_CODE[value.dtype], _DTYPE_CODE[loc.dtype]
     with torch.cuda.device_of(value):
-        nbytes = lib.msda_backward_workspace_bytes(n, s, m, d, lq, l, p, vcode, lcode, flags)
+        nbytes = lib.msda_backward_workspace_bytes(
+            n, s, m, d, lq, l, p, vcode, lcode, flags, levels_host
+        )
         workspace = (
             torch.empty(nbytes, dtype=torch.uint8, device=value.device) if nbytes else None
         )
@@ -178,7 +196,7 @@ def ms_deform_attn_bwd(
             grad_output.data_ptr(), value.data_ptr(), shapes.data_ptr(), lsi.data_ptr(),
             loc.data_ptr(), attn.data_ptr(), grad_value.data_ptr(), grad_loc.data_ptr(),
             grad_attn.data_ptr(), workspace.data_ptr() if nbytes else None, nbytes,
-            n, s, m, d, lq, l, p, vcode, lcode, flags, _stream_ptr(value.device),
+            n, s, m, d, lq, l, p, vcode, lcode, flags, levels_host, _stream_ptr(value.device),
         )
     _lib.check(rc, "msda_backward")
     return grad_value, grad_loc.to(loc_dtype), grad_attn.to(attn_dtype)
