@@ -20,6 +20,10 @@
 // per workgroup, accumulates the tile in LDS (no float atomics there either) and stores it once.
 #pragma once
 
+#ifndef MSDA_K4_PIPE
+#define MSDA_K4_PIPE 0
+#endif
+
 #include <cstdlib>
 #include <initializer_list>
 #include <type_traits>
@@ -102,16 +106,25 @@ __device__ __forceinline__ LevelInfo load_level(const int64_t* __restrict__ shap
   return r;
 }
 
-// One staged sampling point occupies 2 (forward) or 3 (backward) 16-byte LDS slots:
-//   slot 0: the four corner weights, multiplied by the attention weight, 0 for a corner outside
-//           the level;
-//   slot 1: the four corner byte offsets relative to the batch element's value slab (head offset
-//           included, lane offset not); they are multiples of 16, and bit 0 is set when the
-//           corner lies inside the level;
-//   slot 2: (backward only) {lx, ly, attn * W, attn * H}, lx/ly being the fractional parts.
+// One staged sampling point occupies 2 or 3 16-byte LDS slots (see StageKind):
+//   weights:   the four corner weights, multiplied by the attention weight, 0 for a corner
+//              outside the level (not staged by the binned backward, which never uses them);
+//   offsets:   the four corner byte offsets relative to the batch element's value slab (head
+//              offset included, lane offset not); they are multiples of 16, and bit 0 is set
+//              when the corner lies inside the level;
+//   fractions: (backward only) {lx, ly, attn * W, attn * H}, lx/ly being the fractional parts.
 // The LDS stride (in slots) between the point lists of consecutive groups is odd, so the groups
 // of a wave read from disjoint banks.
 __host__ __device__ constexpr int group_stride_slots(int LP, int slots) { return (slots * LP) | 1; }
+
+// Lanes that share one query in the backward query kernel.  Rows of 8+ chunks are split two
+// chunks per lane (lane, lane + lanes): the per-point work that does not depend on the channel
+// count (LDS reads, address arithmetic, bilinear algebra, cross-lane sums) is then paid by half
+// as many lanes, and 4 lanes x 16 bytes still make whole 64-byte L1 accesses.
+#ifndef MSDA_K3_WIDE
+#define MSDA_K3_WIDE 1
+#endif
+__host__ __device__ constexpr int query_lanes(int G) { return (MSDA_K3_WIDE && G >= 8) ? G / 2 : G; }
 
 // One scatter record (16 bytes): what the tile kernel needs to redo the footprint of a point.
 //   x = query index | level << 28, y = attention weight, z/w = normalised location (x, y) as f32
@@ -135,6 +148,8 @@ struct BinPlan {
   int n_qblocks;    // ceil(Lq / qb)
   uint32_t region;  // records per workgroup region
   int tile2d;       // tile geometry (see above)
+  int tw_shift;     // tile2d: log2 of the patch width (the height is TS / width)
+  int staged;       // tile kernel: 1 = LDS-staged rows (bwd_tile_stage_kernel), 0 = gather walk
   int ablate;       // diagnostic runs only: bit mask of phases to skip (results are then wrong)
 };
 
@@ -143,11 +158,12 @@ struct TileMap {  // tile2d only: first tile id and tiles per row of every level
   int tx[kMaxLevelsTuned];
 };
 
-__device__ __forceinline__ void build_tile_map(const LevelInfo* lv, int L, int ts_shift, TileMap& tm) {
-  const int th_shift = ts_shift - 4;
+__device__ __forceinline__ void build_tile_map(const LevelInfo* lv, int L, const BinPlan& plan,
+                                               TileMap& tm) {
+  const int tw_shift = plan.tw_shift, th_shift = plan.ts_shift - plan.tw_shift;
   int run = 0;
   for (int l = 0; l < L; ++l) {
-    const int tx = (lv[l].W + 15) >> 4;
+    const int tx = (lv[l].W + (1 << tw_shift) - 1) >> tw_shift;
     const int ty = (lv[l].H + (1 << th_shift) - 1) >> th_shift;
     tm.tstart[l] = run;
     tm.tx[l] = tx;
@@ -156,14 +172,30 @@ __device__ __forceinline__ void build_tile_map(const LevelInfo* lv, int L, int t
   tm.tstart[L] = run;
 }
 
+// tile2d: level and top-left pixel of a tile (level -1 when the id is past the last tile)
+__device__ __forceinline__ void locate_tile(const TileMap& tm, int L, const BinPlan& plan, int tile,
+                                            int& level, int& y0, int& x0) {
+  int l = -1;
+  for (int k = 0; k < L; ++k)
+    if (tile >= tm.tstart[k] && tile < tm.tstart[k + 1]) l = k;
+  level = l;
+  y0 = x0 = 0;
+  if (l >= 0) {
+    const int r = tile - tm.tstart[l];
+    y0 = (r / tm.tx[l]) << (plan.ts_shift - plan.tw_shift);
+    x0 = (r % tm.tx[l]) << plan.tw_shift;
+  }
+}
+
 // tile id and position inside the tile of the pixel (cy, cx) of level l
 __device__ __forceinline__ void pixel_tile(const BinPlan& plan, const TileMap& tm,
                                            const LevelInfo& L_, int l, int cy, int cx,
                                            uint32_t& tile, uint32_t& local) {
   if (plan.tile2d) {
-    const int th_shift = plan.ts_shift - 4;
-    tile = static_cast<uint32_t>(tm.tstart[l] + (cy >> th_shift) * tm.tx[l] + (cx >> 4));
-    local = static_cast<uint32_t>(((cy & ((1 << th_shift) - 1)) << 4) | (cx & 15));
+    const int tw_shift = plan.tw_shift, th_shift = plan.ts_shift - plan.tw_shift;
+    tile = static_cast<uint32_t>(tm.tstart[l] + (cy >> th_shift) * tm.tx[l] + (cx >> tw_shift));
+    local = static_cast<uint32_t>(((cy & ((1 << th_shift) - 1)) << tw_shift) |
+                                  (cx & ((1 << tw_shift) - 1)));
   } else {
     const uint32_t pos = static_cast<uint32_t>(L_.start + cy * L_.W + cx);
     tile = pos >> plan.ts_shift;
@@ -211,14 +243,20 @@ struct EmitCtx {
   const TileMap* tm;
 };
 
+// What a staged point holds: forward {weights, offsets}; backward with atomic scatter {weights,
+// offsets, fractions}; backward with binned scatter {offsets, fractions}.
+enum StageKind { kStageFwd = 0, kStageBwdAtomic = 1, kStageBwdBinned = 2 };
+__host__ __device__ constexpr int stage_slots(int kind) { return kind == kStageBwdAtomic ? 3 : 2; }
+
 // Stages the points of `nq` consecutive queries of head m (first query q_first) into LDS.
-template <typename LT, int SLOTS, bool EMIT>
+template <typename LT, int KIND, bool EMIT>
 __device__ __forceinline__ void stage_chunk(const LevelInfo* lv, const LT* __restrict__ loc,
                                             const LT* __restrict__ attn, uint4* stage, int b,
                                             int q_first, int nq, int m, int M, int Lq, int LP,
                                             int P, int i_first, int nI, int LPB, uint32_t rowb,
                                             uint32_t headb, const EmitCtx& emit) {
   // points i_first .. i_first + nI - 1 of every query; LDS lists are laid out for LPB points
+  constexpr int SLOTS = stage_slots(KIND);
   const int npts = nq * nI;
   const int stride = group_stride_slots(LPB, SLOTS);
   for (int t = threadIdx.x; t < npts; t += 256) {
@@ -239,9 +277,9 @@ __device__ __forceinline__ void stage_chunk(const LevelInfo* lv, const LT* __res
     orec.z = (static_cast<uint32_t>(L_.start + f.pix[2]) * rowb + headb) | (f.valid[2] ? 1u : 0u);
     orec.w = (static_cast<uint32_t>(L_.start + f.pix[3]) * rowb + headb) | (f.valid[3] ? 1u : 0u);
     uint4* dst = stage + g * stride + SLOTS * ii;
-    dst[0] = wrec;
-    dst[1] = orec;
-    if constexpr (SLOTS == 3) {
+    if constexpr (KIND != kStageBwdBinned) dst[0] = wrec;
+    dst[KIND == kStageBwdBinned ? 0 : 1] = orec;
+    if constexpr (KIND != kStageFwd) {
       const float xs = x * static_cast<float>(L_.W) - 0.5f, ys = y * static_cast<float>(L_.H) - 0.5f;
       const float lx = f.any ? xs - floorf(xs) : 0.f, ly = f.any ? ys - floorf(ys) : 0.f;
       uint4 frec;
@@ -249,7 +287,7 @@ __device__ __forceinline__ void stage_chunk(const LevelInfo* lv, const LT* __res
       frec.y = __float_as_uint(ly);
       frec.z = __float_as_uint(a * static_cast<float>(L_.W));
       frec.w = __float_as_uint(a * static_cast<float>(L_.H));
-      dst[2] = frec;
+      dst[SLOTS - 1] = frec;
     }
     if constexpr (EMIT) {
       if (f.any && a != 0.f && emit.records != nullptr) {
@@ -312,8 +350,8 @@ __global__ __launch_bounds__(256) void fwd_tuned_kernel(
   for (int ib = 0; ib < LP; ib += LPB) {
     const int nI = min(LPB, LP - ib);
     if (ib > 0) __syncthreads();
-    stage_chunk<LT, 2, false>(lv, loc, attn, lds, b, q0, nq, m, M, Lq, LP, P, ib, nI, LPB, rowb,
-                              headb, EmitCtx{});
+    stage_chunk<LT, kStageFwd, false>(lv, loc, attn, lds, b, q0, nq, m, M, Lq, LP, P, ib, nI, LPB,
+                                      rowb, headb, EmitCtx{});
     __syncthreads();
     if (live) {
 #pragma unroll 4
@@ -356,31 +394,44 @@ __device__ __forceinline__ float group_sum(float v) {
   return v;
 }
 
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_u32(uint32_t v) {
+  return static_cast<uint32_t>(
+      __builtin_amdgcn_update_dpp(0, static_cast<int>(v), CTRL, ROW_MASK, 0xF, true));
+}
+
+// inclusive prefix sum over the 64 lanes of a wave, on the DPP path
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t x) {
+  x += dpp_u32<0x111, 0xF>(x);  // row_shr:1
+  x += dpp_u32<0x112, 0xF>(x);  // row_shr:2
+  x += dpp_u32<0x114, 0xF>(x);  // row_shr:4
+  x += dpp_u32<0x118, 0xF>(x);  // row_shr:8
+  x += dpp_u32<0x142, 0xA>(x);  // row_bcast15 into rows 1 and 3
+  x += dpp_u32<0x143, 0xC>(x);  // row_bcast31 into rows 2 and 3
+  return x;
+}
+
 // Exclusive scan of data[0..n) in LDS by the whole 256-thread workgroup; returns the total.
-// tmp: 256 words of LDS.  Ends with a barrier.
+// tmp: 4 words of LDS.  Starts and ends with a barrier.
 __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t* data, int n, uint32_t* tmp) {
   const int per = (n + 255) / 256;
   const int lo = min(static_cast<int>(threadIdx.x) * per, n), hi = min(lo + per, n);
   uint32_t sum = 0;
   for (int i = lo; i < hi; ++i) sum += data[i];
-  tmp[threadIdx.x] = sum;
+  const uint32_t incl = wave_inclusive_scan(sum);
+  __syncthreads();  // tmp may still be read from a previous call
+  if ((threadIdx.x & 63) == 63) tmp[threadIdx.x >> 6] = incl;
   __syncthreads();
-  // Hillis-Steele over the 256 partials
-  for (int s = 1; s < 256; s <<= 1) {
-    const uint32_t add = threadIdx.x >= static_cast<unsigned>(s) ? tmp[threadIdx.x - s] : 0u;
-    __syncthreads();
-    tmp[threadIdx.x] += add;
-    __syncthreads();
-  }
-  uint32_t run = tmp[threadIdx.x] - sum;  // exclusive prefix of this thread's segment
-  const uint32_t total = tmp[255];
+  const uint32_t t0 = tmp[0], t1 = tmp[1], t2 = tmp[2], t3 = tmp[3];
+  const int wave = threadIdx.x >> 6;
+  uint32_t run = incl - sum + (wave > 0 ? t0 : 0u) + (wave > 1 ? t1 : 0u) + (wave > 2 ? t2 : 0u);
   for (int i = lo; i < hi; ++i) {
     const uint32_t c = data[i];
     data[i] = run;
     run += c;
   }
   __syncthreads();
-  return total;
+  return t0 + t1 + t2 + t3;
 }
 
 
@@ -396,7 +447,11 @@ __global__ __launch_bounds__(256) void bwd_query_kernel(
     BinPlan plan) {
   constexpr int CPL = Chunk<VT>::kCPL;
   constexpr int D = G * CPL;
-  constexpr int GPB = 256 / G;
+  constexpr int GQ = query_lanes(G);  // lanes per query
+  constexpr int NC = G / GQ;          // 16-byte chunks of a row per lane: lane, lane + GQ, ...
+  constexpr int GPB = 256 / GQ;
+  constexpr int KIND = MODE == 1 ? kStageBwdBinned : kStageBwdAtomic;
+  constexpr int SL = stage_slots(KIND);
   extern __shared__ uint4 lds[];
   __shared__ LevelInfo lv[kMaxLevelsTuned];
   __shared__ TileMap tm;
@@ -411,15 +466,15 @@ __global__ __launch_bounds__(256) void bwd_query_kernel(
   if (threadIdx.x < L) lv[threadIdx.x] = load_level(shapes, lsi, threadIdx.x, S);
   __syncthreads();
   if (MODE == 1 && plan.tile2d) {
-    if (threadIdx.x == 0) build_tile_map(lv, L, plan.ts_shift, tm);
+    if (threadIdx.x == 0) build_tile_map(lv, L, plan, tm);
     __syncthreads();
   }
 
   const uint32_t rowb = static_cast<uint32_t>(head_major ? 1 : M) * D * sizeof(VT);
   const uint32_t headb = static_cast<uint32_t>(m) * (head_major ? S : 1) * D * sizeof(VT);
   uint4* stage = lds;
-  const int stage_slots = GPB * group_stride_slots(LPB, 3);
-  uint32_t* tile_cnt = reinterpret_cast<uint32_t*>(lds + stage_slots);
+  const int stage_total = GPB * group_stride_slots(LPB, SL);
+  uint32_t* tile_cnt = reinterpret_cast<uint32_t*>(lds + stage_total);
   uint32_t* tile_off = tile_cnt + plan.n_tiles;
   EmitCtx emit{};
 
@@ -463,7 +518,7 @@ __global__ __launch_bounds__(256) void bwd_query_kernel(
     __syncthreads();
   }
 
-  const int g = threadIdx.x / G, lane = threadIdx.x % G;
+  const int g = threadIdx.x / GQ, lane = threadIdx.x % GQ;
   const int64_t slab_elems = static_cast<int64_t>(b) * S * M * D;
   const char* vb = reinterpret_cast<const char*>(value) + slab_elems * static_cast<int64_t>(sizeof(VT));
   const uint32_t lane_b = lane * 16;
@@ -474,39 +529,45 @@ __global__ __launch_bounds__(256) void bwd_query_kernel(
   for (int ib = 0; ib < LP; ib += LPB) {
     const int nq = min(GPB, qb_n - c0);
     const int nI = min(LPB, LP - ib);
-    stage_chunk<LT, 3, MODE == 1>(lv, loc, attn, stage, b, qb0 + c0, nq, m, M, Lq, LP, P, ib, nI,
-                                  LPB, rowb, headb, emit);
+    stage_chunk<LT, KIND, MODE == 1>(lv, loc, attn, stage, b, qb0 + c0, nq, m, M, Lq, LP, P, ib,
+                                     nI, LPB, rowb, headb, emit);
     __syncthreads();
     // lanes of groups past the end redo the last group (no writes) so that every DPP row is full
     const bool live = g < nq;
     const int gg = live ? g : nq - 1;
-    const uint4* r = stage + gg * group_stride_slots(LPB, 3);
+    const uint4* r = stage + gg * group_stride_slots(LPB, SL);
     const int64_t triple = (static_cast<int64_t>(b) * Lq + qb0 + c0 + gg) * M + m;
-    float go[CPL];
-    Chunk<VT>::load(reinterpret_cast<const char*>(grad_out) + (triple * D + lane * CPL) * sizeof(VT), go);
+    float go[NC][CPL];
+#pragma unroll
+    for (int j = 0; j < NC; ++j)
+      Chunk<VT>::load(reinterpret_cast<const char*>(grad_out) + triple * D * sizeof(VT) +
+                          (lane + j * GQ) * 16, go[j]);
 
-    // G points per pass: after the pass lane j of the group keeps the results of point i0 + j, so
-    // the group writes G consecutive grad_attn / grad_loc elements with one store each
-    for (int i0 = 0; i0 < nI; i0 += G) {
+    // GQ points per pass: after the pass lane j of the group keeps the results of point i0 + j,
+    // so the group writes GQ consecutive grad_attn / grad_loc elements with one store each
+    for (int i0 = 0; i0 < nI; i0 += GQ) {
       float keep_sv = 0.f, keep_sx = 0.f, keep_sy = 0.f;
 #pragma unroll
-      for (int k = 0; k < G; ++k) {
+      for (int k = 0; k < GQ; ++k) {
         const int i = min(i0 + k, nI - 1);  // a pass past the end redoes the last point (unused)
-        const uint4 wr = r[3 * i], orr = r[3 * i + 1], fr = r[3 * i + 2];
+        const uint4 orr = r[SL * i + SL - 2], fr = r[SL * i + SL - 1];
         const uint32_t oraw[4] = {orr.x, orr.y, orr.z, orr.w};
         const float lx = __uint_as_float(fr.x), ly = __uint_as_float(fr.y);
         const float aW = __uint_as_float(fr.z), aH = __uint_as_float(fr.w);
         const float hx = 1.f - lx, hy = 1.f - ly;
-        float v[4][CPL];
+        float v[4][NC][CPL];
         uint32_t o[4];
 #pragma unroll
         for (int c4 = 0; c4 < 4; ++c4) {
           o[c4] = (oraw[c4] & ~15u) + lane_b;
-          if (plan.ablate & 4) {
 #pragma unroll
-            for (int c = 0; c < CPL; ++c) v[c4][c] = __uint_as_float(o[c4] + c);
-          } else {
-            Chunk<VT>::load(vb + o[c4], v[c4]);
+          for (int j = 0; j < NC; ++j) {
+            if (plan.ablate & 4) {
+#pragma unroll
+              for (int c = 0; c < CPL; ++c) v[c4][j][c] = __uint_as_float(o[c4] + c);
+            } else {
+              Chunk<VT>::load(vb + o[c4] + j * GQ * 16, v[c4][j]);
+            }
           }
         }
         float dot[4];
@@ -514,30 +575,34 @@ __global__ __launch_bounds__(256) void bwd_query_kernel(
         for (int c4 = 0; c4 < 4; ++c4) {
           float d = 0.f;
 #pragma unroll
-          for (int c = 0; c < CPL; ++c) d = fmaf(go[c], v[c4][c], d);
+          for (int j = 0; j < NC; ++j)
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) d = fmaf(go[j][c], v[c4][j][c], d);
           dot[c4] = (oraw[c4] & 1u) ? d : 0.f;  // a corner outside the level contributes nothing
         }
         if constexpr (MODE == 0) {
+          const uint4 wr = r[SL * i];
           const float aw[4] = {__uint_as_float(wr.x), __uint_as_float(wr.y),
                                __uint_as_float(wr.z), __uint_as_float(wr.w)};
 #pragma unroll
           for (int c4 = 0; c4 < 4; ++c4) {
             if (live && aw[c4] != 0.f && i0 + k < nI) {
-              float* dst = gv_acc + slab_elems + o[c4] / sizeof(VT);
 #pragma unroll
-              for (int c = 0; c < CPL; ++c) atomicAdd(dst + c, aw[c4] * go[c]);
+              for (int j = 0; j < NC; ++j) {
+                float* dst = gv_acc + slab_elems + (o[c4] + j * GQ * 16) / sizeof(VT);
+#pragma unroll
+                for (int c = 0; c < CPL; ++c) atomicAdd(dst + c, aw[c4] * go[j][c]);
+              }
             }
           }
-        } else {
-          (void)wr;
         }
         // w = {hy*hx, hy*lx, ly*hx, ly*lx}; dw/dx = {-hy, hy, -ly, ly}; dw/dy = {-hx, -lx, hx, lx}
         float sv = hy * fmaf(hx, dot[0], lx * dot[1]) + ly * fmaf(hx, dot[2], lx * dot[3]);
         float sx = fmaf(hy, dot[1] - dot[0], ly * (dot[3] - dot[2]));
         float sy = fmaf(hx, dot[2] - dot[0], lx * (dot[3] - dot[1]));
-        sv = group_sum<G>(sv);
-        sx = group_sum<G>(sx);
-        sy = group_sum<G>(sy);
+        sv = group_sum<GQ>(sv);
+        sx = group_sum<GQ>(sx);
+        sy = group_sum<GQ>(sy);
         if (lane == k) {
           keep_sv = sv;
           keep_sx = aW * sx;
@@ -571,25 +636,8 @@ __global__ __launch_bounds__(256) void bwd_query_kernel(
 // bucket of each of its positions and accumulates in registers.  The tile is stored from those
 // registers at the end: no accumulator in LDS, no float atomic anywhere.
 // ---------------------------------------------------------------------------------------------
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ uint32_t dpp_u32(uint32_t v) {
-  return static_cast<uint32_t>(
-      __builtin_amdgcn_update_dpp(0, static_cast<int>(v), CTRL, ROW_MASK, 0xF, true));
-}
-
-// inclusive prefix sum over the 64 lanes of a wave, on the DPP path
-__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t x) {
-  x += dpp_u32<0x111, 0xF>(x);  // row_shr:1
-  x += dpp_u32<0x112, 0xF>(x);  // row_shr:2
-  x += dpp_u32<0x114, 0xF>(x);  // row_shr:4
-  x += dpp_u32<0x118, 0xF>(x);  // row_shr:8
-  x += dpp_u32<0x142, 0xA>(x);  // row_bcast15 into rows 1 and 3
-  x += dpp_u32<0x143, 0xC>(x);  // row_bcast31 into rows 2 and 3
-  return x;
-}
-
 template <typename VT, int G>
-__global__ __launch_bounds__(256) void bwd_tile_kernel(
+__global__ __launch_bounds__(256) void bwd_tile_stage_kernel(
     const VT* __restrict__ grad_out, const int64_t* __restrict__ shapes,
     const int64_t* __restrict__ lsi, const uint4* __restrict__ records,
     const uint2* __restrict__ dir, VT* __restrict__ grad_value, int S, int M, int Lq, int L,
@@ -630,16 +678,8 @@ __global__ __launch_bounds__(256) void bwd_tile_kernel(
   for (int i = threadIdx.x; i < TS; i += 256) cnt[i] = 0;
   __syncthreads();
   if (plan.tile2d && threadIdx.x == 0) {
-    build_tile_map(lv, L, plan.ts_shift, tm);
-    int l = -1;
-    for (int k = 0; k < L; ++k)
-      if (tile >= tm.tstart[k] && tile < tm.tstart[k + 1]) l = k;
-    tile_level_s = l;
-    if (l >= 0) {
-      const int r = tile - tm.tstart[l];
-      tile_y0_s = (r / tm.tx[l]) << (plan.ts_shift - 4);
-      tile_x0_s = (r % tm.tx[l]) << 4;
-    }
+    build_tile_map(lv, L, plan, tm);
+    locate_tile(tm, L, plan, tile, tile_level_s, tile_y0_s, tile_x0_s);
   }
   // the non-empty runs of this tile: (record count, first record index inside the slab)
   for (int qbk = threadIdx.x; qbk < plan.n_qblocks; qbk += 256) {
@@ -790,7 +830,8 @@ __global__ __launch_bounds__(256) void bwd_tile_kernel(
       const int l = tile_level_s;
       if (l < 0) break;
       const int local = pg * PPG + p;
-      const int yy = tile_y0_s + (local >> 4), xx = tile_x0_s + (local & 15);
+      const int yy = tile_y0_s + (local >> plan.tw_shift);
+      const int xx = tile_x0_s + (local & ((1 << plan.tw_shift) - 1));
       if (yy >= lv[l].H || xx >= lv[l].W) continue;
       pos = lv[l].start + static_cast<int64_t>(yy) * lv[l].W + xx;
     } else {
@@ -806,6 +847,219 @@ __global__ __launch_bounds__(256) void bwd_tile_kernel(
       Chunk<VT>::store(dst + pl * 16, sum[p]);
     }
   }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Backward, destination side, gather walk: one workgroup per (batch, head, tile of 64 positions)
+//
+// The tile's records are taken in rounds of up to R.  A round bucket-sorts the in-tile corners of
+// its records by destination position in LDS (count, one-wave DPP scan, fill; integer atomics
+// only), which leaves per position a contiguous list of (query, weight) entries.  The 4 lanes
+// that own a position for the whole life of the workgroup then walk its list, U entries at a
+// time, fetch the grad_out rows of those entries straight from global memory (they sit in L2:
+// the queries that hit one patch are neighbours) and accumulate in registers.  No LDS row stage,
+// no float atomics, four barriers per round; the tile is stored from registers at the end.
+// ---------------------------------------------------------------------------------------------
+template <typename VT, int G, int RPT>
+__global__ __launch_bounds__(256) void bwd_tile_gather_kernel(
+    const VT* __restrict__ grad_out, const int64_t* __restrict__ shapes,
+    const int64_t* __restrict__ lsi, const uint4* __restrict__ records,
+    const uint2* __restrict__ dir, VT* __restrict__ grad_value, int S, int M, int Lq, int L,
+    BinPlan plan) {
+  constexpr int CPL = Chunk<VT>::kCPL;
+  constexpr int D = G * CPL;
+  constexpr int PL = 4;                     // lanes per destination position
+  constexpr int TS = 256 / PL;              // positions per tile: one per lane group, = wave size
+  constexpr int NCH = D / (PL * CPL);       // 16-byte chunks of a row per lane
+  constexpr int R = 256 * RPT;              // records per round
+  constexpr int ROWB = D * sizeof(VT);      // bytes of one grad_out row of one head
+#ifndef MSDA_K4_U
+#define MSDA_K4_U (NCH >= 4 ? 2 : 8 / NCH)
+#endif
+  constexpr int U = MSDA_K4_U;              // entries fetched per walk step
+  static_assert(NCH >= 1 && NCH * PL * CPL == D, "head dim must split into 4 lanes of chunks");
+  static_assert(TS == 64, "the bucket scan is one wave wide");
+  extern __shared__ uint4 lds[];
+  __shared__ LevelInfo lv[kMaxLevelsTuned];
+  __shared__ TileMap tm;
+  __shared__ uint32_t n_runs_s;
+  __shared__ uint32_t scan_tmp[4];
+  __shared__ int tile_level_s, tile_y0_s, tile_x0_s;
+
+  uint2* entries = reinterpret_cast<uint2*>(lds);                    // 4 * R
+  uint32_t* cnt = reinterpret_cast<uint32_t*>(entries + 4 * R);      // TS: counts, then cursors
+  uint32_t* start = cnt + TS;                                        // TS + 1
+  uint32_t* run_first = start + TS + 1;                              // n_qblocks + 1
+  uint32_t* run_base = run_first + plan.n_qblocks + 1;               // n_qblocks
+
+  const int b = blockIdx.y;
+  const int m = blockIdx.x % M;
+  const int tile = plan.n_tiles - 1 - blockIdx.x / M;  // coarse (record-heavy) levels first
+  const int64_t slab = static_cast<int64_t>(b) * M + m;
+  if (threadIdx.x < L) lv[threadIdx.x] = load_level(shapes, lsi, threadIdx.x, S);
+  if (threadIdx.x == 0) n_runs_s = 0;
+  if (threadIdx.x < TS) cnt[threadIdx.x] = 0;
+  __syncthreads();
+  if (plan.tile2d && threadIdx.x == 0) {
+    build_tile_map(lv, L, plan, tm);
+    locate_tile(tm, L, plan, tile, tile_level_s, tile_y0_s, tile_x0_s);
+  }
+  // the non-empty runs of this tile: (record count, first record index inside the slab)
+  for (int qbk = threadIdx.x; qbk < plan.n_qblocks; qbk += 256) {
+    const uint2 e = dir[(slab * plan.n_qblocks + qbk) * plan.n_tiles + tile];
+    if (e.y != 0) {
+      const uint32_t at = atomicAdd(&n_runs_s, 1u);
+      run_first[at] = e.y;
+      run_base[at] = static_cast<uint32_t>(qbk) * plan.region + e.x;
+    }
+  }
+  __syncthreads();
+  const int n_runs = static_cast<int>(n_runs_s);
+  const uint32_t total = block_exclusive_scan(run_first, n_runs, scan_tmp);
+  if (threadIdx.x == 0) run_first[n_runs] = total;
+  __syncthreads();
+
+  const uint4* slab_records = records + slab * plan.n_qblocks * static_cast<int64_t>(plan.region);
+  const char* go_slab = reinterpret_cast<const char*>(grad_out) +
+                        (static_cast<int64_t>(b) * Lq * M + m) * ROWB;  // + q * M * ROWB
+  const uint32_t tile_u = static_cast<uint32_t>(tile);
+  const int pg = threadIdx.x / PL, pl = threadIdx.x % PL;
+  const int64_t q_stride = static_cast<int64_t>(M) * ROWB;
+
+  float sum[NCH][CPL];
+#pragma unroll
+  for (int j = 0; j < NCH; ++j)
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) sum[j][c] = 0.f;
+
+  for (uint32_t base = 0; base < total; base += R) {
+    // ---- A: this thread's records of the round: footprints, count the in-tile corners ----
+    uint32_t rq[RPT];
+    uint32_t rloc[RPT];  // 4 bytes: position inside the tile per corner, 0xff = not in this tile
+    float rw[RPT][4];
+#pragma unroll
+    for (int j = 0; j < RPT; ++j) {
+      const uint32_t i = base + j * 256 + threadIdx.x;
+      rloc[j] = 0xffffffffu;
+      rq[j] = 0;
+      if (i < total && !(plan.ablate & 32)) {
+        int lo = 0, hi = n_runs;  // run_first[lo] <= i < run_first[hi]
+        while (hi - lo > 1) {
+          const int mid = (lo + hi) >> 1;
+          if (run_first[mid] <= i) lo = mid; else hi = mid;
+        }
+        const uint4 rec = slab_records[run_base[lo] + (i - run_first[lo])];
+        const int l = static_cast<int>(rec.x >> 28);
+        const LevelInfo L_ = lv[l];
+        const float a = __uint_as_float(rec.y);
+        const Footprint<float> f =
+            footprint<float>(__uint_as_float(rec.z), __uint_as_float(rec.w), L_.H, L_.W);
+        rq[j] = rec.x & 0x0fffffffu;
+        uint32_t packed = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          uint32_t t, local;
+          pixel_tile(plan, tm, L_, l, f.cy[k >> 1], f.cx[k & 1], t, local);
+          const bool in = f.valid[k] && t == tile_u;
+          rw[j][k] = a * f.w[k];
+          if (in) atomicAdd(&cnt[local], 1u);
+          packed |= (in ? local : 0xffu) << (8 * k);
+        }
+        rloc[j] = packed;
+      }
+    }
+    __syncthreads();
+    // ---- B: exclusive scan of the 64 per-position counts by wave 0; cnt becomes the cursor ----
+    if (threadIdx.x < TS) {
+      const uint32_t c = cnt[threadIdx.x];
+      const uint32_t incl = wave_inclusive_scan(c);
+      start[threadIdx.x] = incl - c;
+      cnt[threadIdx.x] = incl - c;
+      if (threadIdx.x == TS - 1) start[TS] = incl;
+    }
+    __syncthreads();
+    // ---- C: fill the buckets ----
+#pragma unroll
+    for (int j = 0; j < RPT; ++j) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const uint32_t local = (rloc[j] >> (8 * k)) & 0xffu;
+        if (local != 0xffu) {
+          const uint32_t at = atomicAdd(&cnt[local], 1u);
+          entries[at] = make_uint2(rq[j], __float_as_uint(rw[j][k]));
+        }
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x < TS) cnt[threadIdx.x] = 0;  // ready for the next round
+    // ---- D: walk the bucket of this lane group's position ----
+    if (!(plan.ablate & 8)) {
+      const uint32_t e0 = start[pg], e1 = start[pg + 1];
+      // software pipeline: the rows of step i+1 are in flight while step i is accumulated
+      float w_cur[U], rv_cur[U][NCH][CPL];
+      const auto fetch = [&](uint32_t e, float (&w)[U], float (&rv)[U][NCH][CPL]) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const uint2 ent = entries[min(e + u, e1 - 1)];
+          w[u] = e + u < e1 ? __uint_as_float(ent.y) : 0.f;  // weight 0: a repeated row adds nothing
+          const char* row = go_slab + static_cast<int64_t>(ent.x) * q_stride + pl * 16;
+#pragma unroll
+          for (int j = 0; j < NCH; ++j) Chunk<VT>::load(row + j * PL * 16, rv[u][j]);
+        }
+      };
+      const auto accumulate = [&](const float (&w)[U], const float (&rv)[U][NCH][CPL]) {
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+          for (int j = 0; j < NCH; ++j)
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) sum[j][c] = fmaf(w[u], rv[u][j][c], sum[j][c]);
+      };
+#if MSDA_K4_PIPE
+      if (e0 < e1) {
+        fetch(e0, w_cur, rv_cur);
+        for (uint32_t e = e0 + U; e < e1; e += U) {
+          float w_nxt[U], rv_nxt[U][NCH][CPL];
+          fetch(e, w_nxt, rv_nxt);
+          accumulate(w_cur, rv_cur);
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            w_cur[u] = w_nxt[u];
+#pragma unroll
+            for (int j = 0; j < NCH; ++j)
+#pragma unroll
+              for (int c = 0; c < CPL; ++c) rv_cur[u][j][c] = rv_nxt[u][j][c];
+          }
+        }
+        accumulate(w_cur, rv_cur);
+      }
+#else
+      for (uint32_t e = e0; e < e1; e += U) {
+        fetch(e, w_cur, rv_cur);
+        accumulate(w_cur, rv_cur);
+      }
+#endif
+    }
+    __syncthreads();
+  }
+
+  // store the position of this lane group: lane pl holds chunks pl, pl + 4, ... of the row
+  int64_t pos;
+  if (plan.tile2d) {
+    const int l = tile_level_s;
+    if (l < 0) return;
+    const int yy = tile_y0_s + (pg >> plan.tw_shift);
+    const int xx = tile_x0_s + (pg & ((1 << plan.tw_shift) - 1));
+    if (yy >= lv[l].H || xx >= lv[l].W) return;
+    pos = lv[l].start + static_cast<int64_t>(yy) * lv[l].W + xx;
+  } else {
+    pos = static_cast<int64_t>(tile) * TS + pg;
+  }
+  if (pos >= S) return;
+  char* dst = reinterpret_cast<char*>(grad_value) +
+              (((static_cast<int64_t>(b) * S + pos) * M + m) * D) * sizeof(VT) + pl * 16;
+#pragma unroll
+  for (int j = 0; j < NCH; ++j) Chunk<VT>::store(dst + j * PL * 16, sum[j]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -845,12 +1099,13 @@ inline bool tuned_shape_ok(int N, int S, int M, int D, int Lq, int L, int P, int
   return true;
 }
 
-// Points staged per pass: the largest multiple of G whose LDS lists (3 slots per point, 256/G
-// groups) stay within ~26 KB, or all L*P points when they fit.
-inline int stage_points_per_pass(int G, int LP) {
+// Points staged per pass: the largest multiple of G (lanes per query) whose LDS lists (`slots`
+// 16-byte slots per point, 256/G groups) stay within ~26 KB, or all L*P points when they fit.
+inline int stage_points_per_pass(int G, int LP, int slots) {
   const int GPB = 256 / G;
   int lpb = G;
-  while (lpb + G <= 4096 && static_cast<int64_t>(GPB) * group_stride_slots(lpb + G, 3) * 16 <= 26 * 1024)
+  while (lpb + G <= 4096 &&
+         static_cast<int64_t>(GPB) * group_stride_slots(lpb + G, slots) * 16 <= 26 * 1024)
     lpb += G;
   return LP <= lpb ? LP : lpb;
 }
@@ -870,26 +1125,28 @@ inline bool make_bin_plan(int N, int S, int M, int D, int Lq, int L, int P,
                           const int64_t* levels_host, BinPlan* plan, size_t* dir_bytes,
                           size_t* rec_bytes) {
   if (D > 64) return false;                  // the LDS row stage of a slice is 256 * D * 4 B
-  const int ts_shift = tile_positions(D) == 512 ? 9 : tile_positions(D) == 256 ? 8 : 7;
+  const bool staged = getenv("MSDA_EXP_TILE_STAGE") != nullptr;
+  const int ts_shift = !staged ? 6 : tile_positions(D) == 256 ? 8 : 7;
+  const int tw_shift = !staged ? 3 : 4;
   const int TS = 1 << ts_shift;
   const int qb = 256;
   const int64_t n_qblocks = (static_cast<int64_t>(Lq) + qb - 1) / qb;
   const int64_t slabs = static_cast<int64_t>(N) * M;
   const auto fits = [&](int64_t nt) {
-    return nt <= 2048 && slabs * n_qblocks * nt * 8 <= (static_cast<int64_t>(1) << 30) &&
+    return nt <= 4096 && slabs * n_qblocks * nt * 8 <= (static_cast<int64_t>(1) << 30) &&
            nt * M <= INT32_MAX;
   };
   int64_t n_tiles = (static_cast<int64_t>(S) + TS - 1) / TS;
   int tile2d = 0;
   if (levels_host != nullptr && getenv("MSDA_EXP_TILE1D") == nullptr) {
-    const int th = TS / 16;
+    const int tw = 1 << tw_shift, th = TS >> tw_shift;
     int64_t total = 0, nt = 0;
     bool ok = true;
     for (int l = 0; l < L; ++l) {
       const int64_t h = levels_host[2 * l], w = levels_host[2 * l + 1];
       if (h < 1 || w < 1 || h > S || w > S) { ok = false; break; }
       total += h * w;
-      nt += ((h + th - 1) / th) * ((w + 15) / 16);
+      nt += ((h + th - 1) / th) * ((w + tw - 1) / tw);
       if (total > S) { ok = false; break; }
     }
     if (ok && total == S && fits(nt)) {
@@ -909,6 +1166,8 @@ inline bool make_bin_plan(int N, int S, int M, int D, int Lq, int L, int P,
   plan->n_qblocks = static_cast<int>(n_qblocks);
   plan->region = static_cast<uint32_t>(region);
   plan->tile2d = tile2d;
+  plan->tw_shift = tw_shift;
+  plan->staged = staged ? 1 : 0;
   plan->ablate = getenv("MSDA_EXP_ABLATE") ? atoi(getenv("MSDA_EXP_ABLATE")) : 0;
   *dir_bytes = (static_cast<size_t>(dir_b) + 255) & ~static_cast<size_t>(255);
   *rec_bytes = static_cast<size_t>(rec_b);
@@ -949,7 +1208,7 @@ int tuned_forward_typed(const void* value, const int64_t* shapes, const int64_t*
                         int L, int P, int G, bool head_major, hipStream_t stream) {
   const int GPB = 256 / G;
   const dim3 grid(static_cast<unsigned>((Lq + GPB - 1) / GPB) * M, N);
-  const int LPB = stage_points_per_pass(G, L * P);
+  const int LPB = stage_points_per_pass(G, L * P, stage_slots(kStageFwd));
   const size_t lds = static_cast<size_t>(GPB) * group_stride_slots(LPB, 2) * 16;
 #define MSDA_TF(GG)                                                                             \
   hipLaunchKernelGGL((fwd_tuned_kernel<VT, LT, GG>), grid, dim3(256), lds, stream,              \
@@ -1002,25 +1261,34 @@ int tuned_backward_typed(const void* grad_out, const void* value, const int64_t*
                          void* grad_loc, void* grad_attn, void* workspace, int N, int S, int M,
                          int D, int Lq, int L, int P, int G, bool allow_binned, bool head_major,
                          const int64_t* levels_host, hipStream_t stream) {
-  const int GPB = 256 / G;
+  const int GQ = query_lanes(G);
+  const int GPB = 256 / GQ;
   const int LP = L * P;
-  const int LPB = stage_points_per_pass(G, LP);
   BinPlan plan{};
   size_t dir_b = 0, rec_b = 0;
   const bool binned =
       allow_binned && make_bin_plan(N, S, M, D, Lq, L, P, levels_host, &plan, &dir_b, &rec_b);
+  const int slots = stage_slots(binned ? kStageBwdBinned : kStageBwdAtomic);
+  const int LPB = stage_points_per_pass(GQ, LP, slots);
   hipError_t e;
 
   if (binned) {
     uint2* dir = static_cast<uint2*>(workspace);
     uint4* records = reinterpret_cast<uint4*>(static_cast<char*>(workspace) + dir_b);
     const dim3 qgrid(static_cast<unsigned>(plan.n_qblocks) * M, N);
-    const size_t qlds = static_cast<size_t>(GPB) * group_stride_slots(LPB, 3) * 16 +
+    const size_t qlds = static_cast<size_t>(GPB) * group_stride_slots(LPB, slots) * 16 +
                         static_cast<size_t>(plan.n_tiles) * 8;
     const dim3 tgrid(static_cast<unsigned>(plan.n_tiles) * M, N);
     const size_t TSz = static_cast<size_t>(1) << plan.ts_shift;
-    const size_t tlds = 256 * static_cast<size_t>(D) * sizeof(VT) + 4 * 256 * 8 +
-                        (3 * TSz + 1) * 4 + 2 * static_cast<size_t>(plan.n_qblocks) * 4;
+#ifndef MSDA_K4_RPT
+#define MSDA_K4_RPT 4
+#endif
+    constexpr int RPT = MSDA_K4_RPT;  // records per thread and round of the gather-walk tile kernel
+    const size_t tlds =
+        plan.staged ? 256 * static_cast<size_t>(D) * sizeof(VT) + 4 * 256 * 8 +
+                          (3 * TSz + 1) * 4 + 2 * static_cast<size_t>(plan.n_qblocks) * 4
+                    : 4 * 256 * RPT * 8 + (2 * TSz + 1) * 4 +
+                          (2 * static_cast<size_t>(plan.n_qblocks) + 1) * 4;
 #define MSDA_TB(GG)                                                                              \
   hipLaunchKernelGGL((bwd_query_kernel<VT, LT, GG, 1>), qgrid, dim3(256), qlds, stream,          \
                      static_cast<const VT*>(grad_out), static_cast<const VT*>(value), shapes,    \
@@ -1028,9 +1296,14 @@ int tuned_backward_typed(const void* grad_out, const void* value, const int64_t*
                      static_cast<LT*>(grad_loc), static_cast<LT*>(grad_attn),                    \
                      static_cast<float*>(nullptr), records, dir, S, M, Lq, L, P, LPB,            \
                      head_major ? 1 : 0, plan);                                                  \
-  hipLaunchKernelGGL((bwd_tile_kernel<VT, GG>), tgrid, dim3(256), tlds, stream,                  \
-                     static_cast<const VT*>(grad_out), shapes, lsi, records, dir,                \
-                     static_cast<VT*>(grad_value), S, M, Lq, L, plan)
+  if (plan.staged)                                                                               \
+    hipLaunchKernelGGL((bwd_tile_stage_kernel<VT, GG>), tgrid, dim3(256), tlds, stream,          \
+                       static_cast<const VT*>(grad_out), shapes, lsi, records, dir,              \
+                       static_cast<VT*>(grad_value), S, M, Lq, L, plan);                         \
+  else                                                                                           \
+    hipLaunchKernelGGL((bwd_tile_gather_kernel<VT, GG, RPT>), tgrid, dim3(256), tlds, stream,    \
+                       static_cast<const VT*>(grad_out), shapes, lsi, records, dir,              \
+                       static_cast<VT*>(grad_value), S, M, Lq, L, plan)
     switch (G) {
       case 4: MSDA_TB(4); break;
       case 8: MSDA_TB(8); break;
@@ -1048,9 +1321,11 @@ int tuned_backward_typed(const void* grad_out, const void* value, const int64_t*
   plan.n_qblocks = (Lq + plan.qb - 1) / plan.qb;
   plan.n_tiles = 0;
   plan.tile2d = 0;
+  plan.tw_shift = 0;
+  plan.staged = 0;
   plan.ablate = 0;
   const dim3 grid(static_cast<unsigned>(plan.n_qblocks) * M, N);
-  const size_t lds = static_cast<size_t>(GPB) * group_stride_slots(LPB, 3) * 16;
+  const size_t lds = static_cast<size_t>(GPB) * group_stride_slots(LPB, slots) * 16;
   const int64_t total = static_cast<int64_t>(N) * S * M * D;
   constexpr bool kDirect = sizeof(VT) == 4;
   float* acc = kDirect ? static_cast<float*>(grad_value) : static_cast<float*>(workspace);
