@@ -124,6 +124,9 @@ __host__ __device__ constexpr int group_stride_slots(int LP, int slots) { return
 #ifndef MSDA_K3_WIDE
 #define MSDA_K3_WIDE 1
 #endif
+#ifndef MSDA_FWD_WIDE
+#define MSDA_FWD_WIDE 1
+#endif
 __host__ __device__ constexpr int query_lanes(int G) { return (MSDA_K3_WIDE && G >= 8) ? G / 2 : G; }
 
 // One scatter record (16 bytes): what the tile kernel needs to redo the footprint of a point.
@@ -235,11 +238,42 @@ __device__ __forceinline__ int footprint_tiles(const Footprint<float>& f, const 
   return n;
 }
 
+// t / d and t % d for small non-negative t (below ~2^20) and d >= 1 without the integer-division
+// instruction sequence: a float estimate, corrected by at most one step.  `inv` = 1.0f / d.
+__device__ __forceinline__ void small_divmod(int t, int d, float inv, int& q, int& r) {
+  q = static_cast<int>((static_cast<float>(t) + 0.5f) * inv);
+  r = t - q * d;
+  if (r < 0) {
+    --q;
+    r += d;
+  } else if (r >= d) {
+    ++q;
+    r -= d;
+  }
+}
+
+// sampling location (x, y) and attention weight of point idx
+template <typename LT>
+__device__ __forceinline__ void load_point(const LT* __restrict__ loc, const LT* __restrict__ attn,
+                                           int64_t idx, float& x, float& y, float& a) {
+  if constexpr (sizeof(LT) == 4) {
+    const float2 xy = *reinterpret_cast<const float2*>(loc + 2 * idx);
+    x = xy.x;
+    y = xy.y;
+  } else {
+    LT pair[2];  // one 4-byte load for the two 16-bit coordinates
+    __builtin_memcpy(pair, loc + 2 * idx, 4);
+    x = Elem<LT>::load(&pair[0]);
+    y = Elem<LT>::load(&pair[1]);
+  }
+  a = Elem<LT>::load(attn + idx);
+}
+
 struct EmitCtx {
   uint4* records;      // this workgroup's record region
   uint32_t* tile_off;  // LDS: exclusive prefix of records per tile inside the region
   uint32_t* tile_cnt;  // LDS: running rank per tile
-  const BinPlan* plan;
+  BinPlan plan;        // by value: a pointer to the kernel argument would force it into scratch
   const TileMap* tm;
 };
 
@@ -259,13 +293,16 @@ __device__ __forceinline__ void stage_chunk(const LevelInfo* lv, const LT* __res
   constexpr int SLOTS = stage_slots(KIND);
   const int npts = nq * nI;
   const int stride = group_stride_slots(LPB, SLOTS);
+  const float inv_nI = 1.0f / static_cast<float>(nI), inv_P = 1.0f / static_cast<float>(P);
   for (int t = threadIdx.x; t < npts; t += 256) {
-    const int g = t / nI, ii = t - g * nI, i = i_first + ii, l = i / P;
+    int g, ii, l, p_unused;
+    small_divmod(t, nI, inv_nI, g, ii);
+    const int i = i_first + ii;
+    small_divmod(i, P, inv_P, l, p_unused);
     const LevelInfo L_ = lv[l];
     const int64_t idx = ((static_cast<int64_t>(b) * Lq + q_first + g) * M + m) * LP + i;
-    const float x = Elem<LT>::load(loc + 2 * idx);
-    const float y = Elem<LT>::load(loc + 2 * idx + 1);
-    const float a = Elem<LT>::load(attn + idx);
+    float x, y, a;
+    load_point(loc, attn, idx, x, y, a);
     const Footprint<float> f = footprint<float>(x, y, L_.H, L_.W);
     uint4 wrec, orec;
     wrec.x = __float_as_uint(a * f.w[0]);
@@ -292,7 +329,7 @@ __device__ __forceinline__ void stage_chunk(const LevelInfo* lv, const LT* __res
     if constexpr (EMIT) {
       if (f.any && a != 0.f && emit.records != nullptr) {
         uint32_t tiles[4] = {0, 0, 0, 0};
-        const int n = footprint_tiles(f, *emit.plan, *emit.tm, L_, l, tiles);
+        const int n = footprint_tiles(f, emit.plan, *emit.tm, L_, l, tiles);
         uint4 rec;
         rec.x = static_cast<uint32_t>(q_first + g) | (static_cast<uint32_t>(l) << 28);
         rec.y = __float_as_uint(a);
@@ -320,7 +357,9 @@ __global__ __launch_bounds__(256) void fwd_tuned_kernel(
     VT* __restrict__ out, int S, int M, int Lq, int L, int P, int LPB, int head_major) {
   constexpr int CPL = Chunk<VT>::kCPL;
   constexpr int D = G * CPL;
-  constexpr int GPB = 256 / G;  // queries per block
+  constexpr int GQ = MSDA_FWD_WIDE ? query_lanes(G) : G;  // lanes per query
+  constexpr int NC = G / GQ;     // 16-byte chunks of a row per lane: lane, lane + GQ, ...
+  constexpr int GPB = 256 / GQ;  // queries per block
   extern __shared__ uint4 lds[];
   __shared__ LevelInfo lv[kMaxLevelsTuned];
 
@@ -335,16 +374,18 @@ __global__ __launch_bounds__(256) void fwd_tuned_kernel(
   // value is (N,S,M,D), or (N,M,S,D) when head_major: bytes between positions / to head m
   const uint32_t rowb = static_cast<uint32_t>(head_major ? 1 : M) * D * sizeof(VT);
   const uint32_t headb = static_cast<uint32_t>(m) * (head_major ? S : 1) * D * sizeof(VT);
-  const int g = threadIdx.x / G, lane = threadIdx.x % G;
+  const int g = threadIdx.x / GQ, lane = threadIdx.x % GQ;
   const bool live = g < nq;
   const char* vb = reinterpret_cast<const char*>(value) +
                    static_cast<int64_t>(b) * S * M * D * static_cast<int64_t>(sizeof(VT));
   const uint32_t lane_b = lane * 16;
   const uint4* rec = lds + g * group_stride_slots(LPB, 2);
 
-  float acc[CPL];
+  float acc[NC][CPL];
 #pragma unroll
-  for (int c = 0; c < CPL; ++c) acc[c] = 0.f;
+  for (int j = 0; j < NC; ++j)
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) acc[j][c] = 0.f;
 
   // the points of a query are staged LPB at a time (all of them at once for the usual L*P)
   for (int ib = 0; ib < LP; ib += LPB) {
@@ -360,19 +401,26 @@ __global__ __launch_bounds__(256) void fwd_tuned_kernel(
         const float w[4] = {__uint_as_float(wr.x), __uint_as_float(wr.y), __uint_as_float(wr.z),
                             __uint_as_float(wr.w)};
         const uint32_t o[4] = {orr.x & ~15u, orr.y & ~15u, orr.z & ~15u, orr.w & ~15u};
-        float v[4][CPL];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) Chunk<VT>::load(vb + (o[k] + lane_b), v[k]);
+        float v[4][NC][CPL];
 #pragma unroll
         for (int k = 0; k < 4; ++k)
 #pragma unroll
-          for (int c = 0; c < CPL; ++c) acc[c] = fmaf(w[k], v[k][c], acc[c]);
+          for (int j = 0; j < NC; ++j) Chunk<VT>::load(vb + (o[k] + lane_b) + j * GQ * 16, v[k][j]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+          for (int j = 0; j < NC; ++j)
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) acc[j][c] = fmaf(w[k], v[k][j][c], acc[j][c]);
       }
     }
   }
   if (!live) return;
   const int64_t triple = (static_cast<int64_t>(b) * Lq + q0 + g) * M + m;
-  Chunk<VT>::store(reinterpret_cast<char*>(out) + (triple * D + lane * CPL) * sizeof(VT), acc);
+#pragma unroll
+  for (int j = 0; j < NC; ++j)
+    Chunk<VT>::store(reinterpret_cast<char*>(out) + triple * D * sizeof(VT) + (lane + j * GQ) * 16,
+                     acc[j]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -483,13 +531,15 @@ __global__ __launch_bounds__(256) void bwd_query_kernel(
     for (int t = threadIdx.x; t < plan.n_tiles; t += 256) tile_cnt[t] = 0;
     __syncthreads();
     const int npts = qb_n * LP;
+    const float inv_LP = 1.0f / static_cast<float>(LP), inv_P = 1.0f / static_cast<float>(P);
     for (int t = threadIdx.x; t < npts; t += 256) {
-      const int g = t / LP, i = t - g * LP, l = i / P;
+      int g, i, l, p_unused;
+      small_divmod(t, LP, inv_LP, g, i);
+      small_divmod(i, P, inv_P, l, p_unused);
       const LevelInfo L_ = lv[l];
       const int64_t idx = ((static_cast<int64_t>(b) * Lq + qb0 + g) * M + m) * LP + i;
-      const float x = Elem<LT>::load(loc + 2 * idx);
-      const float y = Elem<LT>::load(loc + 2 * idx + 1);
-      const float a = Elem<LT>::load(attn + idx);
+      float x, y, a;
+      load_point(loc, attn, idx, x, y, a);
       const Footprint<float> f = footprint<float>(x, y, L_.H, L_.W);
       if (f.any && a != 0.f) {
         uint32_t tiles[4] = {0, 0, 0, 0};
@@ -513,7 +563,7 @@ __global__ __launch_bounds__(256) void bwd_query_kernel(
     emit.records = records + (slab * plan.n_qblocks + qblock) * static_cast<int64_t>(plan.region);
     emit.tile_off = tile_off;
     emit.tile_cnt = tile_cnt;
-    emit.plan = &plan;
+    emit.plan = plan;
     emit.tm = &tm;
     __syncthreads();
   }
@@ -1206,9 +1256,10 @@ template <typename VT, typename LT>
 int tuned_forward_typed(const void* value, const int64_t* shapes, const int64_t* lsi,
                         const void* loc, const void* attn, void* out, int N, int S, int M, int Lq,
                         int L, int P, int G, bool head_major, hipStream_t stream) {
-  const int GPB = 256 / G;
+  const int GQ = MSDA_FWD_WIDE ? query_lanes(G) : G;
+  const int GPB = 256 / GQ;
   const dim3 grid(static_cast<unsigned>((Lq + GPB - 1) / GPB) * M, N);
-  const int LPB = stage_points_per_pass(G, L * P, stage_slots(kStageFwd));
+  const int LPB = stage_points_per_pass(GQ, L * P, stage_slots(kStageFwd));
   const size_t lds = static_cast<size_t>(GPB) * group_stride_slots(LPB, 2) * 16;
 #define MSDA_TF(GG)                                                                             \
   hipLaunchKernelGGL((fwd_tuned_kernel<VT, LT, GG>), grid, dim3(256), lds, stream,              \
