@@ -16,8 +16,9 @@
 // Backward grad_value (the scatter) avoids global float atomics, which run at the memory side
 // at ~1.3 TB/s of added bytes on MI355X.  The query-side kernel appends one 16-byte record per
 // (point, destination tile) to a per-workgroup region, grouped by tile, and publishes a
-// directory; a second kernel owns one destination tile (TS consecutive positions of one head)
-// per workgroup, accumulates the tile in LDS (no float atomics there either) and stores it once.
+// directory; a second kernel owns one destination tile (64 positions of one head) per workgroup,
+// sorts the tile's records by position in LDS and accumulates every position in the registers
+// of the 4 lanes that own it (no float atomics there either), then stores the tile once.
 #pragma once
 
 #ifndef MSDA_K4_PIPE
@@ -130,11 +131,8 @@ __host__ __device__ constexpr int query_lanes(int G) { return (MSDA_K3_WIDE && G
 //   x = query index | level << 28, y = attention weight, z/w = normalised location (x, y) as f32
 constexpr uint32_t kRecInvalid = 0xffffffffu;
 
-// positions per destination tile, by head dim
-#ifndef MSDA_TS_SMALL_D
-#define MSDA_TS_SMALL_D 256
-#endif
-__host__ __device__ constexpr int tile_positions(int D) { return D <= 32 ? MSDA_TS_SMALL_D : 128; }
+constexpr int kTileShift = 6;       // positions per destination tile: 64, one per 4-lane group
+constexpr int kTileWidthShift = 3;  // 2-D tiles are 8 x 8 patches
 
 // Destination tiles of the binned grad_value scatter.  tile2d = 0: a tile is TS consecutive
 // positions of the flattened (level-concatenated) sequence.  tile2d = 1: a tile is a
@@ -149,7 +147,6 @@ struct BinPlan {
   uint32_t region;  // records per workgroup region
   int tile2d;       // tile geometry (see above)
   int tw_shift;     // tile2d: log2 of the patch width (the height is TS / width)
-  int staged;       // tile kernel: 1 = LDS-staged rows (bwd_tile_stage_kernel), 0 = gather walk
   int ablate;       // diagnostic runs only: bit mask of phases to skip (results are then wrong)
 };
 
@@ -675,230 +672,6 @@ __global__ __launch_bounds__(256) void bwd_query_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------
-// Backward, destination side: one workgroup per (batch, head, tile of TS positions)
-//
-// ds_add_f32 runs at ~0.3 lanes/clk/CU on gfx950 (measured; ds_add_u32 does ~12), so the tile is
-// NOT accumulated with LDS float atomics.  Each slice of 256 records (one per thread) is
-// bucketed by destination position with integer LDS atomics (count, DPP scan, fill); the
-// slice's grad_out rows go global -> LDS by LDS-DMA, once per record; then every group of D/8
-// lanes, which owns PPG consecutive positions for the whole life of the workgroup, walks the
-// bucket of each of its positions and accumulates in registers.  The tile is stored from those
-// registers at the end: no accumulator in LDS, no float atomic anywhere.
-// ---------------------------------------------------------------------------------------------
-template <typename VT, int G>
-__global__ __launch_bounds__(256) void bwd_tile_stage_kernel(
-    const VT* __restrict__ grad_out, const int64_t* __restrict__ shapes,
-    const int64_t* __restrict__ lsi, const uint4* __restrict__ records,
-    const uint2* __restrict__ dir, VT* __restrict__ grad_value, int S, int M, int Lq, int L,
-    BinPlan plan) {
-  constexpr int CPL = Chunk<VT>::kCPL;
-  constexpr int D = G * CPL;
-  constexpr int R = 256;                      // records per slice (one per thread)
-  constexpr int ROWB = D * sizeof(VT);        // bytes of one grad_out row of one head
-  constexpr int RPI = 64 / G;                 // rows one wave-wide LDS-DMA instruction moves
-  constexpr int PL = D / 8;                   // lanes per bucket entry, 8 channels each
-  constexpr int PG = 256 / PL;                // entry groups per workgroup
-  constexpr int CPR = (8 * sizeof(VT)) / 16;  // 16-byte chunks a lane reads per row (2 or 1)
-  constexpr int TS = tile_positions(D);       // positions per tile
-  constexpr int PPG = TS / PG;                // positions owned by one entry group
-  extern __shared__ uint4 lds[];
-  __shared__ LevelInfo lv[kMaxLevelsTuned];
-  __shared__ TileMap tm;
-  __shared__ uint32_t n_runs_s, total_s;
-  __shared__ int tile_level_s, tile_y0_s, tile_x0_s;  // tile2d: the patch this workgroup owns
-
-  char* gstage = reinterpret_cast<char*>(lds);                                // R rows
-  uint2* entries = reinterpret_cast<uint2*>(gstage + R * ROWB);               // 4 * R
-  uint32_t* cnt = reinterpret_cast<uint32_t*>(entries + 4 * R);               // TS
-  uint32_t* start = cnt + TS;                                                 // TS + 1
-  uint32_t* cursor = start + TS + 1;                                          // TS
-  uint32_t* run_cnt = cursor + TS;                                            // n_qblocks
-  uint32_t* run_base = run_cnt + plan.n_qblocks;                              // n_qblocks
-
-  const int b = blockIdx.y;
-  const int m = blockIdx.x % M;
-  const int tile = plan.n_tiles - 1 - blockIdx.x / M;  // coarse (record-heavy) levels first
-  const int64_t slab = static_cast<int64_t>(b) * M + m;
-  if (threadIdx.x < L) lv[threadIdx.x] = load_level(shapes, lsi, threadIdx.x, S);
-  if (threadIdx.x == 0) {
-    n_runs_s = 0;
-    total_s = 0;
-  }
-  for (int i = threadIdx.x; i < TS; i += 256) cnt[i] = 0;
-  __syncthreads();
-  if (plan.tile2d && threadIdx.x == 0) {
-    build_tile_map(lv, L, plan, tm);
-    locate_tile(tm, L, plan, tile, tile_level_s, tile_y0_s, tile_x0_s);
-  }
-  // the non-empty runs of this tile: (record count, first record index inside the slab)
-  for (int qbk = threadIdx.x; qbk < plan.n_qblocks; qbk += 256) {
-    const uint2 e = dir[(slab * plan.n_qblocks + qbk) * plan.n_tiles + tile];
-    if (e.y != 0) {
-      const uint32_t at = atomicAdd(&n_runs_s, 1u);
-      run_cnt[at] = e.y;
-      run_base[at] = static_cast<uint32_t>(qbk) * plan.region + e.x;
-      atomicAdd(&total_s, e.y);
-    }
-  }
-  __syncthreads();
-  const int n_runs = static_cast<int>(n_runs_s);
-  const uint32_t total = total_s;
-
-  const int wave = threadIdx.x >> 6, wlane = threadIdx.x & 63;
-  const uint4* slab_records = records + slab * plan.n_qblocks * static_cast<int64_t>(plan.region);
-  const char* go_slab = reinterpret_cast<const char*>(grad_out) +
-                        (static_cast<int64_t>(b) * Lq * M + m) * ROWB;  // + q * M * ROWB
-  const uint32_t tile_u = static_cast<uint32_t>(tile);
-
-  // this thread's position in the run list: record `threadIdx.x + k * R` of the flattened order
-  int run = 0;
-  uint32_t off = threadIdx.x;
-  while (run < n_runs && off >= run_cnt[run]) off -= run_cnt[run++];
-  uint4 rec = make_uint4(kRecInvalid, 0, 0, 0);
-  if (run < n_runs) rec = slab_records[run_base[run] + off];
-
-  const int pg = threadIdx.x / PL, pl = threadIdx.x % PL;
-  float sum[PPG][8];
-#pragma unroll
-  for (int p = 0; p < PPG; ++p)
-#pragma unroll
-    for (int c = 0; c < 8; ++c) sum[p][c] = 0.f;
-
-  for (uint32_t base = 0; base < total; base += R) {
-    // ---- A: prefetch the next slice's record ----
-    off += R;
-    while (run < n_runs && off >= run_cnt[run]) off -= run_cnt[run++];
-    uint4 rec_next = make_uint4(kRecInvalid, 0, 0, 0);
-    if (run < n_runs) rec_next = slab_records[run_base[run] + off];
-
-    // ---- B: grad_out rows of this wave's 64 record slots, global -> LDS ----
-    if (!(plan.ablate & 64))
-#pragma unroll
-    for (int k = 0; k < G; ++k) {
-      const int src = k * RPI + wlane / G;  // lane of the wave that holds the row's record
-      const uint32_t qk = __shfl(rec.x, src, 64);
-      // an empty slot reads row 0 (a valid address); nothing refers to it afterwards
-      const uint32_t q = (qk == kRecInvalid || (plan.ablate & 16)) ? 0u : (qk & 0x0fffffffu);
-      const char* srcp = go_slab + static_cast<int64_t>(q) * M * ROWB + (wlane % G) * 16;
-      char* dstp = gstage + (wave * 64 + k * RPI) * ROWB;  // wave-uniform; lanes land 16 B apart
-      __builtin_amdgcn_global_load_lds(
-          (const __attribute__((address_space(1))) void*)srcp,
-          (__attribute__((address_space(3))) void*)dstp, 16, 0, 0);
-    }
-
-    // ---- C: footprint of the thread's own record, count its in-tile corners per position ----
-    const bool have = rec.x != kRecInvalid && !(plan.ablate & 32);
-    uint32_t loc_pix[4];
-    float loc_w[4];
-    bool in_tile[4] = {false, false, false, false};
-    if (have) {
-      const int l = static_cast<int>(rec.x >> 28);
-      const LevelInfo L_ = lv[l];
-      const float a = __uint_as_float(rec.y);
-      const Footprint<float> f =
-          footprint<float>(__uint_as_float(rec.z), __uint_as_float(rec.w), L_.H, L_.W);
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        uint32_t t;
-        pixel_tile(plan, tm, L_, l, f.cy[k >> 1], f.cx[k & 1], t, loc_pix[k]);
-        in_tile[k] = f.valid[k] && t == tile_u;
-        loc_w[k] = a * f.w[k];
-        if (in_tile[k]) atomicAdd(&cnt[loc_pix[k]], 1u);
-      }
-    }
-    __syncthreads();
-    // ---- D: exclusive scan of the per-position counts.  Every wave scans the whole array
-    //         redundantly (K consecutive counters per lane), so no cross-wave step is needed;
-    //         wave w then publishes the quarter of the result its lanes 16w..16w+15 hold ----
-    {
-      constexpr int K = TS / 64;
-      uint32_t c[K];
-      uint32_t local = 0;
-#pragma unroll
-      for (int j = 0; j < K; ++j) {
-        c[j] = cnt[wlane * K + j];
-        local += c[j];
-      }
-      uint32_t run = wave_inclusive_scan(local) - local;
-      if ((wlane >> 4) == wave) {
-#pragma unroll
-        for (int j = 0; j < K; ++j) {
-          start[wlane * K + j] = run;
-          cursor[wlane * K + j] = run;
-          run += c[j];
-        }
-        if (wlane == 63) start[TS] = run;
-      }
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < TS; i += 256) cnt[i] = 0;  // ready for the next slice
-    // ---- E: fill the buckets ----
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      if (in_tile[k]) {
-        const uint32_t at = atomicAdd(&cursor[loc_pix[k]], 1u);
-        entries[at] = make_uint2(threadIdx.x | (loc_pix[k] << 16), __float_as_uint(loc_w[k]));
-      }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the LDS-DMA rows have landed
-    __syncthreads();
-    // ---- F: every entry group walks the buckets of its own positions ----
-    if (!(plan.ablate & 8)) {
-#pragma unroll
-      for (int p = 0; p < PPG; ++p) {
-        const uint32_t e0 = start[pg * PPG + p], e1 = start[pg * PPG + p + 1];
-        for (uint32_t e = e0; e < e1; ++e) {
-          const uint2 ent = entries[e];
-          const float w = __uint_as_float(ent.y);
-          const char* row = gstage + (ent.x & 0xffffu) * ROWB;
-          float rv[8];
-          if constexpr (CPR == 2) {  // fp32: chunks pl and pl + PL of the row
-            const float4 t0 = *reinterpret_cast<const float4*>(row + pl * 16);
-            const float4 t1 = *reinterpret_cast<const float4*>(row + (pl + PL) * 16);
-            rv[0] = t0.x; rv[1] = t0.y; rv[2] = t0.z; rv[3] = t0.w;
-            rv[4] = t1.x; rv[5] = t1.y; rv[6] = t1.z; rv[7] = t1.w;
-          } else {  // 16-bit: chunk pl holds this lane's 8 channels
-            Chunk<VT>::load(row + pl * 16, rv);
-          }
-#pragma unroll
-          for (int c = 0; c < 8; ++c) sum[p][c] = fmaf(w, rv[c], sum[p][c]);
-        }
-      }
-    }
-    __syncthreads();
-    rec = rec_next;
-  }
-
-  // store the tile from the registers: lane pl of an entry group holds channels
-  // [pl*4, pl*4+4) and [(pl+PL)*4, ...) of its positions (fp32), or [pl*8, pl*8+8) (16-bit)
-  const int64_t row_elems = static_cast<int64_t>(M) * D;
-#pragma unroll
-  for (int p = 0; p < PPG; ++p) {
-    int64_t pos;
-    if (plan.tile2d) {
-      const int l = tile_level_s;
-      if (l < 0) break;
-      const int local = pg * PPG + p;
-      const int yy = tile_y0_s + (local >> plan.tw_shift);
-      const int xx = tile_x0_s + (local & ((1 << plan.tw_shift) - 1));
-      if (yy >= lv[l].H || xx >= lv[l].W) continue;
-      pos = lv[l].start + static_cast<int64_t>(yy) * lv[l].W + xx;
-    } else {
-      pos = static_cast<int64_t>(tile) * TS + pg * PPG + p;
-    }
-    if (pos >= S) continue;
-    char* dst = reinterpret_cast<char*>(grad_value) +
-                (((static_cast<int64_t>(b) * S + pos) * row_elems) + m * D) * sizeof(VT);
-    if constexpr (CPR == 2) {
-      *reinterpret_cast<float4*>(dst + pl * 16) = make_float4(sum[p][0], sum[p][1], sum[p][2], sum[p][3]);
-      *reinterpret_cast<float4*>(dst + (pl + PL) * 16) = make_float4(sum[p][4], sum[p][5], sum[p][6], sum[p][7]);
-    } else {
-      Chunk<VT>::store(dst + pl * 16, sum[p]);
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
 // Backward, destination side, gather walk: one workgroup per (batch, head, tile of 64 positions)
 //
 // The tile's records are taken in rounds of up to R.  A round bucket-sorts the in-tile corners of
@@ -1173,10 +946,8 @@ inline bool all_aligned16(std::initializer_list<const void*> ps) {
 inline bool make_bin_plan(int N, int S, int M, int D, int Lq, int L, int P,
                           const int64_t* levels_host, BinPlan* plan, size_t* dir_bytes,
                           size_t* rec_bytes) {
-  if (D > 64) return false;                  // the LDS row stage of a slice is 256 * D * 4 B
-  const bool staged = getenv("MSDA_EXP_TILE_STAGE") != nullptr;
-  const int ts_shift = !staged ? 6 : tile_positions(D) == 256 ? 8 : 7;
-  const int tw_shift = !staged ? 3 : 4;
+  if (D > 64) return false;                  // accumulators of a position: D / 4 registers per lane
+  const int ts_shift = kTileShift, tw_shift = kTileWidthShift;
   const int TS = 1 << ts_shift;
   const int qb = 256;
   const int64_t n_qblocks = (static_cast<int64_t>(Lq) + qb - 1) / qb;
@@ -1216,7 +987,6 @@ inline bool make_bin_plan(int N, int S, int M, int D, int Lq, int L, int P,
   plan->region = static_cast<uint32_t>(region);
   plan->tile2d = tile2d;
   plan->tw_shift = tw_shift;
-  plan->staged = staged ? 1 : 0;
   plan->ablate = getenv("MSDA_EXP_ABLATE") ? atoi(getenv("MSDA_EXP_ABLATE")) : 0;
   *dir_bytes = (static_cast<size_t>(dir_b) + 255) & ~static_cast<size_t>(255);
   *rec_bytes = static_cast<size_t>(rec_b);
@@ -1334,11 +1104,8 @@ int tuned_backward_typed(const void* grad_out, const void* value, const int64_t*
 #define MSDA_K4_RPT 4
 #endif
     constexpr int RPT = MSDA_K4_RPT;  // records per thread and round of the gather-walk tile kernel
-    const size_t tlds =
-        plan.staged ? 256 * static_cast<size_t>(D) * sizeof(VT) + 4 * 256 * 8 +
-                          (3 * TSz + 1) * 4 + 2 * static_cast<size_t>(plan.n_qblocks) * 4
-                    : 4 * 256 * RPT * 8 + (2 * TSz + 1) * 4 +
-                          (2 * static_cast<size_t>(plan.n_qblocks) + 1) * 4;
+    const size_t tlds = 4 * 256 * RPT * 8 + (2 * TSz + 1) * 4 +
+                        (2 * static_cast<size_t>(plan.n_qblocks) + 1) * 4;
 #define MSDA_TB(GG)                                                                              \
   hipLaunchKernelGGL((bwd_query_kernel<VT, LT, GG, 1>), qgrid, dim3(256), qlds, stream,          \
                      static_cast<const VT*>(grad_out), static_cast<const VT*>(value), shapes,    \
@@ -1346,14 +1113,9 @@ int tuned_backward_typed(const void* grad_out, const void* value, const int64_t*
                      static_cast<LT*>(grad_loc), static_cast<LT*>(grad_attn),                    \
                      static_cast<float*>(nullptr), records, dir, S, M, Lq, L, P, LPB,            \
                      head_major ? 1 : 0, plan);                                                  \
-  if (plan.staged)                                                                               \
-    hipLaunchKernelGGL((bwd_tile_stage_kernel<VT, GG>), tgrid, dim3(256), tlds, stream,          \
-                       static_cast<const VT*>(grad_out), shapes, lsi, records, dir,              \
-                       static_cast<VT*>(grad_value), S, M, Lq, L, plan);                         \
-  else                                                                                           \
-    hipLaunchKernelGGL((bwd_tile_gather_kernel<VT, GG, RPT>), tgrid, dim3(256), tlds, stream,    \
-                       static_cast<const VT*>(grad_out), shapes, lsi, records, dir,              \
-                       static_cast<VT*>(grad_value), S, M, Lq, L, plan)
+  hipLaunchKernelGGL((bwd_tile_gather_kernel<VT, GG, RPT>), tgrid, dim3(256), tlds, stream,      \
+                     static_cast<const VT*>(grad_out), shapes, lsi, records, dir,                \
+                     static_cast<VT*>(grad_value), S, M, Lq, L, plan)
     switch (G) {
       case 4: MSDA_TB(4); break;
       case 8: MSDA_TB(8); break;
@@ -1372,7 +1134,6 @@ int tuned_backward_typed(const void* grad_out, const void* value, const int64_t*
   plan.n_tiles = 0;
   plan.tile2d = 0;
   plan.tw_shift = 0;
-  plan.staged = 0;
   plan.ablate = 0;
   const dim3 grid(static_cast<unsigned>(plan.n_qblocks) * M, N);
   const size_t lds = static_cast<size_t>(GPB) * group_stride_slots(LPB, slots) * 16;
