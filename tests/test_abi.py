@@ -120,7 +120,7 @@ def test_workspace_bytes():
     assert ws(1, 640, 2, 32, 2, 2, 2, _lib.BF16, _lib.BF16, _lib.FLAG_DETERMINISTIC) == 0
     # binned path (Cityscapes shapes, batch 8): directory + 64 B per sampled point
     n, s, m, d, l, p = 8, 43008, 8, 32, 3, 4
-    tiles = -(-s // 256)
+    tiles = -(-s // 64)  # 64 positions per destination tile
     qblocks = -(-s // 256)
     dir_bytes = n * m * qblocks * tiles * 8
     rec_bytes = n * m * qblocks * 256 * l * p * 4 * 16
@@ -130,18 +130,18 @@ def test_workspace_bytes():
     assert ws(n, s, m, d, s, l, p, _lib.BF16, _lib.F32, _lib.FLAG_ATOMIC_SCATTER) == n * s * m * d * 4
     # invalid arguments give 0
     assert ws(0, s, m, d, s, l, p, _lib.F32, _lib.F32, 0) == 0
-    # host level shapes select 16x16 patches: same count here (every extent divides by 16) ...
+    # host level shapes select 8x8 patches: same count here (every extent divides by 8) ...
     host = (ctypes.c_int64 * 6)(128, 256, 64, 128, 32, 64)
     assert ws_h(n, s, m, d, s, l, p, _lib.F32, _lib.F32, 0, host) == ws(n, s, m, d, s, l, p, _lib.F32, _lib.F32, 0)
-    # ... more tiles when the extents are ragged (3 levels of 20x24, 10x12, 5x6: 4+1+1 patches
-    # against ceil(630/256) = 3 runs), and the 1-D plan when the table does not cover S
+    # ... more tiles when the extents are ragged (3 levels of 20x24, 10x12, 5x6: 9+4+1 patches
+    # against ceil(630/64) = 10 runs), and the 1-D plan when the table does not cover S
     s2 = 20 * 24 + 10 * 12 + 5 * 6
     ragged = (ctypes.c_int64 * 6)(20, 24, 10, 12, 5, 6)
     base = ws(1, s2, m, d, s2, l, p, _lib.F32, _lib.F32, 0)
     qb2 = -(-s2 // 256)
     r256 = lambda x: -(-x // 256) * 256
     assert (ws_h(1, s2, m, d, s2, l, p, _lib.F32, _lib.F32, 0, ragged) - base
-            == r256(m * qb2 * 6 * 8) - r256(m * qb2 * 3 * 8))
+            == r256(m * qb2 * 14 * 8) - r256(m * qb2 * 10 * 8))
     wrong = (ctypes.c_int64 * 6)(20, 24, 10, 12, 5, 7)
     assert ws_h(1, s2, m, d, s2, l, p, _lib.F32, _lib.F32, 0, wrong) == base
 

@@ -67,6 +67,9 @@ struct Footprint {
   int cy[2];    // clamped rows y0, y0+1    (corner k sits at row cy[k >> 1], column cx[k & 1])
   int cx[2];    // clamped columns x0, x0+1
   bool valid[4];  // corner lies inside the level (and the point inside the skirt)
+  bool vy[2];   // row y0 / y0+1 lies inside the level: valid[k] = vy[k >> 1] && vx[k & 1]
+  bool vx[2];   // column x0 / x0+1 lies inside the level
+  CT lx, ly;    // fractional parts of the pixel coordinates (0 when !any)
   bool any;     // false when the point lies outside the (-1, H) x (-1, W) skirt: contributes nothing
 };
 
@@ -92,6 +95,12 @@ __device__ __forceinline__ Footprint<CT> footprint(CT locx, CT locy, int H, int 
   const CT w[4] = {hy * hx, hy * lx, ly * hx, ly * lx};
   const CT dx[4] = {-hy, hy, -ly, ly};
   const CT dy[4] = {-hx, -lx, hx, lx};
+  f.vy[0] = vy0;
+  f.vy[1] = vy1;
+  f.vx[0] = vx0;
+  f.vx[1] = vx1;
+  f.lx = lx;
+  f.ly = ly;
   f.cy[0] = yc0;
   f.cy[1] = yc1;
   f.cx[0] = xc0;

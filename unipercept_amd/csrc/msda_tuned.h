@@ -33,6 +33,15 @@
 
 namespace msda {
 
+// Diagnostic builds only (-DMSDA_ABLATE=<bits>): phases to leave out so that their cost can be
+// read off a timing difference; the results are then wrong.  1 query kernel: count + emit,
+// 2 query kernel: grad_loc / grad_attn stores, 4 query kernel: value gather, 8 tile kernel: bucket
+// walk, 32 tile kernel: bucket sort.
+#ifndef MSDA_ABLATE
+#define MSDA_ABLATE 0
+#endif
+constexpr int kAblate = MSDA_ABLATE;
+
 constexpr int kNotTuned = INT32_MIN;
 constexpr int MSDA_TUNED_ELAYOUT = -8;  // = MSDA_ELAYOUT of the public header
 constexpr int kMaxLevelsTuned = 16;
@@ -147,7 +156,7 @@ struct BinPlan {
   uint32_t region;  // records per workgroup region
   int tile2d;       // tile geometry (see above)
   int tw_shift;     // tile2d: log2 of the patch width (the height is TS / width)
-  int ablate;       // diagnostic runs only: bit mask of phases to skip (results are then wrong)
+  int in_order;     // always 1; a run-time value on purpose, see the value gather of bwd_query_kernel
 };
 
 struct TileMap {  // tile2d only: first tile id and tiles per row of every level
@@ -200,36 +209,46 @@ __device__ __forceinline__ void pixel_tile(const BinPlan& plan, const TileMap& t
   }
 }
 
-// Distinct destination tiles of a footprint (at most 4), compacted into tiles[]; returns the
-// count.  Tiles at or beyond plan.n_tiles (host and device level tables disagree) are dropped.
-__device__ __forceinline__ int footprint_tiles(const Footprint<float>& f, const BinPlan& plan,
-                                               const TileMap& tm, const LevelInfo& L_, int l,
-                                               uint32_t (&tiles)[4]) {
-  uint32_t t[4];
-  bool ok[4];
+// Destination tiles of the four corners of a footprint: t[k] is the tile of corner k, keep[k]
+// says whether a record goes to it (the corner counts and no earlier corner has the same tile).
+// Tiles at or beyond plan.n_tiles (host and device level tables disagree) are dropped.
+__device__ __forceinline__ void footprint_tiles(const Footprint<float>& f, const BinPlan& plan,
+                                                const TileMap& tm, const LevelInfo& L_, int l,
+                                                uint32_t (&t)[4], bool (&keep)[4]) {
+  const uint32_t n_tiles = static_cast<uint32_t>(plan.n_tiles);
+  if (plan.tile2d) {
+    // a patch is a product of a row range and a column range, so rows and columns dedupe
+    // separately: the second row (column) adds tiles only if it is inside the level and falls in
+    // another patch row (column) than a first one that counts
+    const int tw_shift = plan.tw_shift, th_shift = plan.ts_shift - plan.tw_shift;
+    const int ty0 = f.cy[0] >> th_shift, ty1 = f.cy[1] >> th_shift;
+    const int tx0 = f.cx[0] >> tw_shift, tx1 = f.cx[1] >> tw_shift;
+    const int txl = tm.tx[l];
+    const uint32_t base0 = static_cast<uint32_t>(tm.tstart[l] + ty0 * txl);
+    const uint32_t base1 = static_cast<uint32_t>(tm.tstart[l] + ty1 * txl);
+    const bool r0 = f.vy[0], r1 = f.vy[1] && !(f.vy[0] && ty1 == ty0);
+    const bool c0 = f.vx[0], c1 = f.vx[1] && !(f.vx[0] && tx1 == tx0);
+    t[0] = base0 + tx0;
+    t[1] = base0 + tx1;
+    t[2] = base1 + tx0;
+    t[3] = base1 + tx1;
+    keep[0] = r0 && c0 && t[0] < n_tiles;
+    keep[1] = r0 && c1 && t[1] < n_tiles;
+    keep[2] = r1 && c0 && t[2] < n_tiles;
+    keep[3] = r1 && c1 && t[3] < n_tiles;
+  } else {
+    bool ok[4];
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    uint32_t local;
-    pixel_tile(plan, tm, L_, l, f.cy[k >> 1], f.cx[k & 1], t[k], local);
-    ok[k] = f.valid[k] && t[k] < static_cast<uint32_t>(plan.n_tiles);
+    for (int k = 0; k < 4; ++k) {
+      t[k] = static_cast<uint32_t>(L_.start + f.pix[k]) >> plan.ts_shift;
+      ok[k] = f.valid[k] && t[k] < n_tiles;
+    }
+    keep[0] = ok[0];
+    keep[1] = ok[1] && !(ok[0] && t[0] == t[1]);
+    keep[2] = ok[2] && !(ok[0] && t[0] == t[2]) && !(ok[1] && t[1] == t[2]);
+    keep[3] = ok[3] && !(ok[0] && t[0] == t[3]) && !(ok[1] && t[1] == t[3]) &&
+              !(ok[2] && t[2] == t[3]);
   }
-  // keep corner k when it counts and no earlier counting corner has the same tile
-  const bool keep0 = ok[0];
-  const bool keep1 = ok[1] && !(ok[0] && t[0] == t[1]);
-  const bool keep2 = ok[2] && !(ok[0] && t[0] == t[2]) && !(ok[1] && t[1] == t[2]);
-  const bool keep3 = ok[3] && !(ok[0] && t[0] == t[3]) && !(ok[1] && t[1] == t[3]) &&
-                     !(ok[2] && t[2] == t[3]);
-  const bool keep[4] = {keep0, keep1, keep2, keep3};
-  int n = 0;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    // compact without dynamic indexing
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-      if (keep[k] && j == n) tiles[j] = t[k];
-    n += keep[k] ? 1 : 0;
-  }
-  return n;
 }
 
 // t / d and t % d for small non-negative t (below ~2^20) and d >= 1 without the integer-division
@@ -311,19 +330,18 @@ __device__ __forceinline__ void stage_chunk(const LevelInfo* lv, const LT* __res
     if constexpr (KIND != kStageBwdBinned) dst[0] = wrec;
     dst[KIND == kStageBwdBinned ? 0 : 1] = orec;
     if constexpr (KIND != kStageFwd) {
-      const float xs = x * static_cast<float>(L_.W) - 0.5f, ys = y * static_cast<float>(L_.H) - 0.5f;
-      const float lx = f.any ? xs - floorf(xs) : 0.f, ly = f.any ? ys - floorf(ys) : 0.f;
       uint4 frec;
-      frec.x = __float_as_uint(lx);
-      frec.y = __float_as_uint(ly);
+      frec.x = __float_as_uint(f.lx);
+      frec.y = __float_as_uint(f.ly);
       frec.z = __float_as_uint(a * static_cast<float>(L_.W));
       frec.w = __float_as_uint(a * static_cast<float>(L_.H));
       dst[SLOTS - 1] = frec;
     }
     if constexpr (EMIT) {
       if (f.any && a != 0.f && emit.records != nullptr) {
-        uint32_t tiles[4] = {0, 0, 0, 0};
-        const int n = footprint_tiles(f, emit.plan, *emit.tm, L_, l, tiles);
+        uint32_t tiles[4];
+        bool keep[4];
+        footprint_tiles(f, emit.plan, *emit.tm, L_, l, tiles, keep);
         uint4 rec;
         rec.x = static_cast<uint32_t>(q_first + g) | (static_cast<uint32_t>(l) << 28);
         rec.y = __float_as_uint(a);
@@ -331,9 +349,9 @@ __device__ __forceinline__ void stage_chunk(const LevelInfo* lv, const LT* __res
         rec.w = __float_as_uint(y);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          if (j < n) {
-            const uint32_t rank = atomicAdd(&emit.tile_cnt[tiles[j]], 1u);
-            emit.records[emit.tile_off[tiles[j]] + rank] = rec;
+          if (keep[j]) {
+            const uint32_t at = emit.tile_off[tiles[j]] + atomicAdd(&emit.tile_cnt[tiles[j]], 1u);
+            if (at < emit.plan.region) emit.records[at] = rec;  // always true: a bug stays in the region
           }
         }
       }
@@ -456,14 +474,15 @@ __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t x) {
 }
 
 // Exclusive scan of data[0..n) in LDS by the whole 256-thread workgroup; returns the total.
-// tmp: 4 words of LDS.  Starts and ends with a barrier.
+// tmp: 4 words of LDS.  Starts with a barrier (data may have been written by any thread, tmp may
+// still be read from a previous call) and ends with one.
 __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t* data, int n, uint32_t* tmp) {
   const int per = (n + 255) / 256;
   const int lo = min(static_cast<int>(threadIdx.x) * per, n), hi = min(lo + per, n);
+  __syncthreads();
   uint32_t sum = 0;
   for (int i = lo; i < hi; ++i) sum += data[i];
   const uint32_t incl = wave_inclusive_scan(sum);
-  __syncthreads();  // tmp may still be read from a previous call
   if ((threadIdx.x & 63) == 63) tmp[threadIdx.x >> 6] = incl;
   __syncthreads();
   const uint32_t t0 = tmp[0], t1 = tmp[1], t2 = tmp[2], t3 = tmp[3];
@@ -499,7 +518,7 @@ __global__ __launch_bounds__(256) void bwd_query_kernel(
   extern __shared__ uint4 lds[];
   __shared__ LevelInfo lv[kMaxLevelsTuned];
   __shared__ TileMap tm;
-  __shared__ uint32_t scan_tmp[256];
+  __shared__ uint32_t scan_tmp[4];
 
   const int LP = L * P;
   const int b = blockIdx.y;
@@ -522,7 +541,7 @@ __global__ __launch_bounds__(256) void bwd_query_kernel(
   uint32_t* tile_off = tile_cnt + plan.n_tiles;
   EmitCtx emit{};
 
-  if (MODE == 1 && !(plan.ablate & 1)) {
+  if (MODE == 1 && !(kAblate & 1)) {
     // ---- count the records of this workgroup per destination tile ----
     for (int t = threadIdx.x; t < plan.n_tiles; t += 256) tile_cnt[t] = 0;
     __syncthreads();
@@ -538,11 +557,12 @@ __global__ __launch_bounds__(256) void bwd_query_kernel(
       load_point(loc, attn, idx, x, y, a);
       const Footprint<float> f = footprint<float>(x, y, L_.H, L_.W);
       if (f.any && a != 0.f) {
-        uint32_t tiles[4] = {0, 0, 0, 0};
-        const int n = footprint_tiles(f, plan, tm, L_, l, tiles);
+        uint32_t tiles[4];
+        bool keep[4];
+        footprint_tiles(f, plan, tm, L_, l, tiles, keep);
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          if (j < n) atomicAdd(&tile_cnt[tiles[j]], 1u);
+          if (keep[j]) atomicAdd(&tile_cnt[tiles[j]], 1u);
       }
     }
     __syncthreads();
@@ -550,7 +570,6 @@ __global__ __launch_bounds__(256) void bwd_query_kernel(
     const int64_t slab = static_cast<int64_t>(b) * M + m;
     uint2* dir_row = dir + (slab * plan.n_qblocks + qblock) * plan.n_tiles;
     for (int t = threadIdx.x; t < plan.n_tiles; t += 256) tile_off[t] = tile_cnt[t];
-    __syncthreads();
     block_exclusive_scan(tile_off, plan.n_tiles, scan_tmp);
     for (int t = threadIdx.x; t < plan.n_tiles; t += 256) {
       dir_row[t] = make_uint2(tile_off[t], tile_cnt[t]);
@@ -608,11 +627,15 @@ __global__ __launch_bounds__(256) void bwd_query_kernel(
           o[c4] = (oraw[c4] & ~15u) + lane_b;
 #pragma unroll
           for (int j = 0; j < NC; ++j) {
-            if (plan.ablate & 4) {
+            // plan.in_order is always 1, but the compiler cannot know: every gather then sits
+            // in a basic block of its own and is issued in program order, all loads of a point
+            // back to back.  Left to itself the scheduler interleaves them with the arithmetic
+            // to save registers, which keeps fewer rows in flight (measured: 3 % slower).
+            if (plan.in_order && !(kAblate & 4)) {
+              Chunk<VT>::load(vb + o[c4] + j * GQ * 16, v[c4][j]);
+            } else {
 #pragma unroll
               for (int c = 0; c < CPL; ++c) v[c4][j][c] = __uint_as_float(o[c4] + c);
-            } else {
-              Chunk<VT>::load(vb + o[c4] + j * GQ * 16, v[c4][j]);
             }
           }
         }
@@ -656,7 +679,7 @@ __global__ __launch_bounds__(256) void bwd_query_kernel(
         }
       }
       const int i = i0 + lane;
-      if (i < nI && live && !(plan.ablate & 2)) {
+      if (i < nI && live && !(kAblate & 2)) {
         const int64_t gi = triple * LP + ib + i;
         Elem<LT>::store(grad_attn + gi, keep_sv);
         if constexpr (sizeof(LT) == 4) {
@@ -729,7 +752,8 @@ __global__ __launch_bounds__(256) void bwd_tile_gather_kernel(
   // the non-empty runs of this tile: (record count, first record index inside the slab)
   for (int qbk = threadIdx.x; qbk < plan.n_qblocks; qbk += 256) {
     const uint2 e = dir[(slab * plan.n_qblocks + qbk) * plan.n_tiles + tile];
-    if (e.y != 0) {
+    // (a run that does not fit its region can only come from a corrupted directory: skipped)
+    if (e.y != 0 && e.x <= plan.region && e.y <= plan.region - e.x) {
       const uint32_t at = atomicAdd(&n_runs_s, 1u);
       run_first[at] = e.y;
       run_base[at] = static_cast<uint32_t>(qbk) * plan.region + e.x;
@@ -764,7 +788,7 @@ __global__ __launch_bounds__(256) void bwd_tile_gather_kernel(
       const uint32_t i = base + j * 256 + threadIdx.x;
       rloc[j] = 0xffffffffu;
       rq[j] = 0;
-      if (i < total && !(plan.ablate & 32)) {
+      if (i < total && !(kAblate & 32)) {
         int lo = 0, hi = n_runs;  // run_first[lo] <= i < run_first[hi]
         while (hi - lo > 1) {
           const int mid = (lo + hi) >> 1;
@@ -815,7 +839,7 @@ __global__ __launch_bounds__(256) void bwd_tile_gather_kernel(
     __syncthreads();
     if (threadIdx.x < TS) cnt[threadIdx.x] = 0;  // ready for the next round
     // ---- D: walk the bucket of this lane group's position ----
-    if (!(plan.ablate & 8)) {
+    if (!(kAblate & 8)) {
       const uint32_t e0 = start[pg], e1 = start[pg + 1];
       // software pipeline: the rows of step i+1 are in flight while step i is accumulated
       float w_cur[U], rv_cur[U][NCH][CPL];
@@ -987,7 +1011,7 @@ inline bool make_bin_plan(int N, int S, int M, int D, int Lq, int L, int P,
   plan->region = static_cast<uint32_t>(region);
   plan->tile2d = tile2d;
   plan->tw_shift = tw_shift;
-  plan->ablate = getenv("MSDA_EXP_ABLATE") ? atoi(getenv("MSDA_EXP_ABLATE")) : 0;
+  plan->in_order = 1;
   *dir_bytes = (static_cast<size_t>(dir_b) + 255) & ~static_cast<size_t>(255);
   *rec_bytes = static_cast<size_t>(rec_b);
   return true;
@@ -1134,7 +1158,7 @@ int tuned_backward_typed(const void* grad_out, const void* value, const int64_t*
   plan.n_tiles = 0;
   plan.tile2d = 0;
   plan.tw_shift = 0;
-  plan.ablate = 0;
+  plan.in_order = 1;
   const dim3 grid(static_cast<unsigned>(plan.n_qblocks) * M, N);
   const size_t lds = static_cast<size_t>(GPB) * group_stride_slots(LPB, slots) * 16;
   const int64_t total = static_cast<int64_t>(N) * S * M * D;
