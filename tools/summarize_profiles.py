@@ -25,7 +25,7 @@ def counters(name):
 
 stats = kernel_stats()
 pmc = {}
-for name in ("FETCH_SIZE", "WRITE_SIZE", "TCC_HIT_sum"):
+for name in ("FETCH_SIZE", "WRITE_SIZE", "TCC_HIT_sum", "GRBM_GUI_ACTIVE", "SQ_WAVES"):
     for k, d in counters(name).items():
         pmc.setdefault(k, {}).update(d)
 bench = json.loads(open(f"{out}/bench.json").read().strip().splitlines()[-1])
@@ -39,6 +39,14 @@ for k, d in pmc.items():
         d["hbm_write_bytes"] = d["WRITE_SIZE"] * 1024
     if "TCC_HIT_sum" in d:
         d["l2_hit_rate"] = d["TCC_HIT_sum"] / (d["TCC_HIT_sum"] + d["TCC_MISS_sum"])
+    if "TA_TA_BUSY_sum" in d and d.get("GRBM_GUI_ACTIVE"):
+        # TA_TA_BUSY is summed over the 256 CUs, GRBM_GUI_ACTIVE over the 8 XCDs
+        cyc = d["GRBM_GUI_ACTIVE"] / 8
+        d["ta_busy_frac"] = d["TA_TA_BUSY_sum"] / 256 / cyc
+        d["l1_accesses_per_clk_per_cu"] = d["TCP_TOTAL_CACHE_ACCESSES_sum"] / 256 / cyc
+        if "SQ_INSTS_VALU" in d:
+            # a wave64 VALU instruction occupies its SIMD for 4 cycles; 1024 SIMDs
+            d["valu_busy_frac"] = d["SQ_INSTS_VALU"] * 4 / (1024 * cyc)
 json.dump(summary, open(f"{out}/summary_{tag}.json", "w"), indent=1)
 with open(f"{out}/summary_{tag}.md", "w") as f:
     f.write(f"# rocprofv3 summary `{tag}`\n\nbench line (un-profiled run, same command):\n\n```\n{json.dumps(bench)}\n```\n\n")
@@ -49,4 +57,9 @@ with open(f"{out}/summary_{tag}.md", "w") as f:
     f.write("| kernel | FETCH_SIZE KiB | WRITE_SIZE KiB | HBM read B (x2 corrected) | HBM write B | L2 hit rate | TCC_EA0_RDREQ | TCC_EA0_WRREQ |\n|---|---|---|---|---|---|---|---|\n")
     for k, d in pmc.items():
         f.write(f"| `{k}` | {d.get('FETCH_SIZE', 0):.0f} | {d.get('WRITE_SIZE', 0):.0f} | {d.get('hbm_read_bytes_x2', 0):.3e} | {d.get('hbm_write_bytes', 0):.3e} | {d.get('l2_hit_rate', 0):.3f} | {d.get('TCC_EA0_RDREQ_sum', 0):.3e} | {d.get('TCC_EA0_WRREQ_sum', 0):.3e} |\n")
+    f.write("\n## pipeline counters per launch\n\n| kernel | cycles (GRBM_GUI_ACTIVE / 8 XCDs) | TA busy | L1 accesses / clk / CU | VALU busy (4 clk per wave instr, 1024 SIMDs) | VALU instr | SALU instr | LDS instr | VMEM rd | VMEM wr | waves |\n|---|---|---|---|---|---|---|---|---|---|---|\n")
+    for k, d in pmc.items():
+        if "ta_busy_frac" not in d:
+            continue
+        f.write(f"| `{k}` | {d['GRBM_GUI_ACTIVE'] / 8:.3e} | {d['ta_busy_frac']:.2f} | {d['l1_accesses_per_clk_per_cu']:.2f} | {d.get('valu_busy_frac', 0):.2f} | {d.get('SQ_INSTS_VALU', 0):.3e} | {d.get('SQ_INSTS_SALU', 0):.3e} | {d.get('SQ_INSTS_LDS', 0):.3e} | {d.get('SQ_INSTS_VMEM_RD', 0):.3e} | {d.get('SQ_INSTS_VMEM_WR', 0):.3e} | {d.get('SQ_WAVES', 0):.0f} |\n")
 print(open(f"{out}/summary_{tag}.md").read())
