@@ -79,6 +79,9 @@ def main() -> None:
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch override")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fwd-only", action="store_true")
+    ap.add_argument("--packed", action="store_true",
+                    help="time the packed locations+weights entry point (MultiScaleFlashAttnFunction's "
+                    "kernels) instead of the separate-tensor one")
     ap.add_argument("--no-head-major", action="store_true",
                     help="gather from the (N,S,M,D) value as given instead of a per-head copy")
     args = ap.parse_args()
@@ -126,6 +129,15 @@ def main() -> None:
     head_major = not args.no_head_major and _ops.head_major_supported(value, loc)
     flags = _lib.FLAG_VALUE_HEAD_MAJOR if head_major else 0
 
+    packed = None
+    if args.packed:
+        packed = torch.cat([loc.flatten(-3), attn.flatten(-2)], dim=-1).contiguous()
+        if not _ops.packed_points_supported(value, packed, w.n_levels):
+            raise SystemExit(f"{w.name}: the kernels do not take the packed form for this shape")
+        fwd_p = torch.ops.unipercept.ms_flash_attn_fwd
+        bwd_p = torch.ops.unipercept.ms_flash_attn_bwd
+        del loc, attn
+
     bucket = None
     comm_stream = None
     if distributed:
@@ -141,11 +153,14 @@ def main() -> None:
         if i is not None:
             ev[i][0].record()
         v = to_head_major(value) if head_major else value
-        out = fwd(v, shapes, lsi, loc, attn, flags)
+        out = fwd_p(v, shapes, lsi, packed, flags) if args.packed else fwd(v, shapes, lsi, loc, attn, flags)
         if i is not None:
             ev[i][1].record()
         if not args.fwd_only:
-            bwd(grad_out, v, shapes, lsi, loc, attn, flags)
+            if args.packed:
+                bwd_p(grad_out, v, shapes, lsi, packed, flags)
+            else:
+                bwd(grad_out, v, shapes, lsi, loc, attn, flags)
         if i is not None:
             ev[i][2].record()
         del out, v
@@ -191,7 +206,7 @@ def main() -> None:
         traffic = None
         try:
             rec = json.loads((ROOT / "profiles" / "hbm_traffic.json").read_text()).get(f"{w.name}:{args.dist}")
-            if rec is not None and batch == w.batch:
+            if rec is not None and batch == w.batch and not args.packed:
                 traffic = rec[dom]
         except (OSError, ValueError, KeyError):
             traffic = None
@@ -213,6 +228,9 @@ def main() -> None:
             "data": "synthetic",
             "config": {
                 "workload": w.name,
+                "entry_point": "MultiScaleFlashAttnFunction kernels (packed locations+weights, read in place)"
+                if args.packed
+                else "MultiScaleDeformAttnFunction kernels (separate locations / weights)",
                 "levels": [list(x) for x in w.levels],
                 "heads": w.heads,
                 "head_dim": w.head_dim,

@@ -66,6 +66,15 @@ enum {
    * grad_value is (N, S, M, D) either way.  A head's slab then spreads over all L2 channels and
    * x-neighbouring bilinear corners are contiguous: the gathers run ~25 % faster on MI355X. */
   MSDA_FLAG_VALUE_HEAD_MAJOR = 8,
+  /* Locations and weights come as ONE packed tensor (N, Lq, M, 3*L*P): per (batch, query, head)
+   * row the L*P (x, y) pairs, then the L*P weights — the input of the reference's
+   * `MultiScaleFlashAttnFunction`
+   * (tests/unipercept/nn/layers/test_nn_layers_deform_attn.py:105-111,186-192 of the reference:
+   * `cat([loc.flatten(-3), attn.flatten(-2)], -1)`).  Pass it as `loc`; `attn` is ignored.  In
+   * msda_backward `grad_loc` receives the packed gradient (same layout) and `grad_attn` is
+   * ignored.  Weights are used as given (no softmax), as that test compares against
+   * `reference.deform_attn` with the same weights.  Where msda_packed_points_supported() says so. */
+  MSDA_FLAG_PACKED_POINTS = 16,
 };
 
 /* Library ABI version (bumped when a signature changes). */
@@ -103,6 +112,13 @@ int msda_forward(const void* value, const int64_t* shapes_dev, const int64_t* ls
  */
 int msda_head_major_supported(int N, int S, int M, int D, int Lq, int L, int P, int dtype_val,
                               int dtype_loc);
+
+/*
+ * 1 when msda_forward and msda_backward take MSDA_FLAG_PACKED_POINTS for this problem (tuned
+ * kernels, even L*P), else 0; callers then unpack into separate location / weight tensors.
+ */
+int msda_packed_points_supported(int N, int S, int M, int D, int Lq, int L, int P, int dtype_val,
+                                 int dtype_loc);
 
 /*
  * Copies value between the two layouts: to_head_major != 0: src (N,S,M,D) -> dst (N,M,S,D);

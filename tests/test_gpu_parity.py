@@ -164,6 +164,76 @@ def test_scatter_tile_geometries_agree(case, monkeypatch):
         assert np.abs(b.cpu().double().numpy() - w_).max() <= BWD_ATOL_F32
 
 
+def _flash(value, shapes, lsi, loc, attn, grad_out):
+    from unipercept_amd.deform_attn import MultiScaleFlashAttnFunction
+
+    v = value.clone().requires_grad_(True)
+    packed = torch.cat([loc.flatten(-3), attn.flatten(-2)], dim=-1).requires_grad_(True)
+    out = MultiScaleFlashAttnFunction.apply(v, shapes, lsi, packed, 64)
+    out.backward(grad_out)
+    lp2 = loc[0, 0, 0].numel()
+    g_loc = packed.grad[..., :lp2].reshape(loc.shape)
+    g_attn = packed.grad[..., lp2:].reshape(attn.shape)
+    return tuple(t.detach().cpu().double().numpy() for t in (out, v.grad, g_loc, g_attn))
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16", "bf16_locf32"])
+@pytest.mark.parametrize("case", ["enc_L3P4", "enc_L4P8", "heads3_d64"])
+def test_flash_packed_points_direct(case, dtype, monkeypatch):
+    """The packed locations+weights tensor is read by the kernels as it is (even L*P, tuned head
+    dims): same results as the oracle, and as the unpacking route."""
+    from unipercept_amd.deform_attn import _ops
+
+    n, m, d, lq, levels, p = MID[case]
+    value, shapes, lsi, loc, attn, grad_out = make_inputs(
+        n, m, d, lq, levels, p, dtype=torch.float32, seed=23, device="cuda"
+    )
+    value = value * 100
+    if dtype != "f32":
+        value, grad_out = value.bfloat16(), grad_out.bfloat16()
+        if dtype == "bf16":
+            loc, attn = loc.bfloat16(), attn.bfloat16()
+    packed = torch.cat([loc.flatten(-3), attn.flatten(-2)], dim=-1)
+    assert _ops.packed_points_supported(value, packed, len(levels))
+    want = _oracle64(value, shapes, loc, attn, grad_out)
+    got = _flash(value, shapes, lsi, loc, attn, grad_out)
+    monkeypatch.setenv("MSDA_NO_PACKED_POINTS", "1")
+    unpacked = _flash(value, shapes, lsi, loc, attn, grad_out)
+    tols = (FWD_ATOL_F32, BWD_ATOL_F32, BWD_ATOL_F32, BWD_ATOL_F32)
+    for name, g, u, w_, atol, rel in zip(
+        ("out", "grad_value", "grad_loc", "grad_attn"), got, unpacked, want, tols,
+        (2**-7, 2**-7, 2**-6, 2**-7),
+    ):
+        if dtype == "f32":
+            assert np.abs(g - w_).max() <= atol, name
+            assert np.abs(g - u).max() <= 1e-5, name
+        else:
+            scale = np.abs(w_).max() + 1e-30
+            assert np.abs(g - w_).max() / scale <= rel, name
+            assert np.abs(g - u).max() / scale <= rel, name
+
+
+def test_flash_packed_points_fallbacks():
+    """Odd L*P and head dims without a tuned kernel take the unpacking route; results agree
+    with the oracle either way."""
+    from unipercept_amd.deform_attn import _ops
+
+    for case in ("d16_ragged",):  # L = 3, P = 3
+        n, m, d, lq, levels, p = MID[case]
+        value, shapes, lsi, loc, attn, grad_out = make_inputs(
+            n, m, d, lq, levels, p, dtype=torch.float32, seed=29, device="cuda"
+        )
+        packed = torch.cat([loc.flatten(-3), attn.flatten(-2)], dim=-1)
+        assert not _ops.packed_points_supported(value, packed, len(levels))
+        want = _oracle64(value, shapes, loc, attn, grad_out)
+        got = _flash(value, shapes, lsi, loc, attn, grad_out)
+        assert np.abs(got[0] - want[0]).max() <= FWD_ATOL_F32
+        for g, w_ in zip(got[1:], want[1:]):
+            assert np.abs(g - w_).max() <= BWD_ATOL_F32
+    v30 = torch.rand(1, 640, 2, 30, device="cuda")
+    assert not _ops.packed_points_supported(v30, torch.rand(1, 5, 2, 3 * 2 * 2, device="cuda"), 2)
+
+
 def test_head_major_layout_matches_position_major(monkeypatch):
     """The per-head value copy is a pure re-layout: identical results either way."""
     from unipercept_amd import _lib

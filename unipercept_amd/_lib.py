@@ -18,6 +18,7 @@ FLAG_DETERMINISTIC = 1
 FLAG_GENERIC = 2
 FLAG_ATOMIC_SCATTER = 4
 FLAG_VALUE_HEAD_MAJOR = 8
+FLAG_PACKED_POINTS = 16
 
 # every symbol include/msda.h declares
 EXPORTS = (
@@ -26,6 +27,7 @@ EXPORTS = (
     "msda_check_im2col_step",
     "msda_forward",
     "msda_head_major_supported",
+    "msda_packed_points_supported",
     "msda_value_relayout",
     "msda_backward_workspace_bytes",
     "msda_backward",
@@ -51,6 +53,8 @@ def _declare(lib: ctypes.CDLL) -> None:
     lib.msda_forward.argtypes = [c_vp] * 6 + [c_int] * 7 + [c_int, c_int, c_int, c_vp]
     lib.msda_head_major_supported.restype = c_int
     lib.msda_head_major_supported.argtypes = [c_int] * 9
+    lib.msda_packed_points_supported.restype = c_int
+    lib.msda_packed_points_supported.argtypes = [c_int] * 9
     lib.msda_value_relayout.restype = c_int
     lib.msda_value_relayout.argtypes = [c_vp, c_vp] + [c_int] * 6 + [c_vp]
     lib.msda_backward_workspace_bytes.restype = c_sz

@@ -150,7 +150,8 @@ const char* msda_error_string(int code) {
     case MSDA_EWORKSPACE: return "msda: workspace missing, misaligned or too small";
     case MSDA_ESTEP: return "msda: im2col_step must be >= 1 and min(N, im2col_step) must divide N";
     case MSDA_ELEVELS: return "msda: too many levels/points (L <= 16, L*P <= 128)";
-    case MSDA_ELAYOUT: return "msda: head-major value layout is not supported for this shape/path";
+    case MSDA_ELAYOUT:
+      return "msda: head-major value / packed point layout is not supported for this shape/path";
     default:
       return code > 0 ? hipGetErrorString(static_cast<hipError_t>(code)) : "msda: unknown error";
   }
@@ -165,11 +166,12 @@ int msda_check_im2col_step(int N, int im2col_step) {
 int msda_forward(const void* value, const int64_t* shapes_dev, const int64_t* lsi_dev,
                  const void* loc, const void* attn, void* out, int N, int S, int M, int D, int Lq,
                  int L, int P, int dtype_val, int dtype_loc, int flags, void* hip_stream) {
-  if (!value || !shapes_dev || !lsi_dev || !loc || !attn || !out) return MSDA_ENULL;
+  const bool packed = (flags & MSDA_FLAG_PACKED_POINTS) != 0;  // then `attn` is not looked at
+  if (!value || !shapes_dev || !lsi_dev || !loc || (!attn && !packed) || !out) return MSDA_ENULL;
   const int rc = check_common(N, S, M, D, Lq, L, P, dtype_val, dtype_loc);
   if (rc != MSDA_OK) return rc;
   if (!aligned(value, elem_size(dtype_val)) || !aligned(out, elem_size(dtype_val)) ||
-      !aligned(loc, elem_size(dtype_loc)) || !aligned(attn, elem_size(dtype_loc)) ||
+      !aligned(loc, elem_size(dtype_loc)) || (!packed && !aligned(attn, elem_size(dtype_loc))) ||
       !aligned(shapes_dev, 8) || !aligned(lsi_dev, 8))
     return MSDA_EALIGN;
   const Dims d{N, S, M, D, Lq, L, P};
@@ -178,10 +180,10 @@ int msda_forward(const void* value, const int64_t* shapes_dev, const int64_t* ls
   if (!(flags & MSDA_FLAG_GENERIC)) {
     const int t = tuned_forward(value, shapes_dev, lsi_dev, loc, attn, out, N, S, M, D, Lq, L, P,
                                 dtype_val, dtype_loc, (flags & MSDA_FLAG_VALUE_HEAD_MAJOR) != 0,
-                                stream);
+                                packed, stream);
     if (t != kNotTuned) return t;
   }
-  if (flags & MSDA_FLAG_VALUE_HEAD_MAJOR) return MSDA_ELAYOUT;
+  if ((flags & MSDA_FLAG_VALUE_HEAD_MAJOR) || packed) return MSDA_ELAYOUT;
   switch (dtype_val) {
     case MSDA_F32:
       return fwd_generic<float, float>(value, shapes_dev, lsi_dev, loc, attn, out, d, stream);
@@ -203,6 +205,15 @@ int msda_head_major_supported(int N, int S, int M, int D, int Lq, int L, int P, 
                               int dtype_loc) {
   if (check_common(N, S, M, D, Lq, L, P, dtype_val, dtype_loc) != MSDA_OK) return 0;
   return head_major_supported(N, S, M, D, Lq, L, P, dtype_val, dtype_loc) ? 1 : 0;
+}
+
+int msda_packed_points_supported(int N, int S, int M, int D, int Lq, int L, int P, int dtype_val,
+                                 int dtype_loc) {
+  if (check_common(N, S, M, D, Lq, L, P, dtype_val, dtype_loc) != MSDA_OK) return 0;
+  int G;
+  return tuned_shape_ok(N, S, M, D, Lq, L, P, dtype_val, dtype_loc, &G) && packed_shape_ok(L, P)
+             ? 1
+             : 0;
 }
 
 int msda_value_relayout(const void* src, void* dst, int N, int S, int M, int D, int dtype_val,
@@ -245,15 +256,17 @@ int msda_backward(const void* grad_out, const void* value, const int64_t* shapes
                   void* grad_loc, void* grad_attn, void* workspace, size_t workspace_bytes, int N,
                   int S, int M, int D, int Lq, int L, int P, int dtype_val, int dtype_loc,
                   int flags, const int64_t* shapes_host, void* hip_stream) {
-  if (!grad_out || !value || !shapes_dev || !lsi_dev || !loc || !attn || !grad_value ||
-      !grad_loc || !grad_attn)
+  const bool packed = (flags & MSDA_FLAG_PACKED_POINTS) != 0;  // attn / grad_attn not looked at
+  if (!grad_out || !value || !shapes_dev || !lsi_dev || !loc || !grad_value || !grad_loc ||
+      (!packed && (!attn || !grad_attn)))
     return MSDA_ENULL;
   const int rc = check_common(N, S, M, D, Lq, L, P, dtype_val, dtype_loc);
   if (rc != MSDA_OK) return rc;
   const size_t ev = elem_size(dtype_val), el = elem_size(dtype_loc);
   if (!aligned(grad_out, ev) || !aligned(value, ev) || !aligned(grad_value, ev) ||
-      !aligned(loc, el) || !aligned(attn, el) || !aligned(grad_loc, el) ||
-      !aligned(grad_attn, el) || !aligned(shapes_dev, 8) || !aligned(lsi_dev, 8))
+      !aligned(loc, el) || !aligned(grad_loc, el) ||
+      (!packed && (!aligned(attn, el) || !aligned(grad_attn, el))) || !aligned(shapes_dev, 8) ||
+      !aligned(lsi_dev, 8))
     return MSDA_EALIGN;
   const size_t need =
       msda_backward_workspace_bytes(N, S, M, D, Lq, L, P, dtype_val, dtype_loc, flags,
@@ -268,10 +281,11 @@ int msda_backward(const void* grad_out, const void* value, const int64_t* shapes
     const int t = tuned_backward(grad_out, value, shapes_dev, lsi_dev, loc, attn, grad_value,
                                  grad_loc, grad_attn, workspace, N, S, M, D, Lq, L, P, dtype_val,
                                  dtype_loc, !(flags & MSDA_FLAG_ATOMIC_SCATTER),
-                                 (flags & MSDA_FLAG_VALUE_HEAD_MAJOR) != 0, shapes_host, stream);
+                                 (flags & MSDA_FLAG_VALUE_HEAD_MAJOR) != 0, packed, shapes_host,
+                                 stream);
     if (t != kNotTuned) return t;
   }
-  if (flags & MSDA_FLAG_VALUE_HEAD_MAJOR) return MSDA_ELAYOUT;
+  if ((flags & MSDA_FLAG_VALUE_HEAD_MAJOR) || packed) return MSDA_ELAYOUT;
 #define MSDA_BWD(VT, LT, GT)                                                                  \
   bwd_generic<VT, LT, GT>(grad_out, value, shapes_dev, lsi_dev, loc, attn, grad_value,        \
                           grad_loc, grad_attn, workspace, d, det, stream)

@@ -265,21 +265,32 @@ __device__ __forceinline__ void small_divmod(int t, int d, float inv, int& q, in
   }
 }
 
-// sampling location (x, y) and attention weight of point idx
+// Elements between the (batch, query, head) rows of the location and weight arrays: 2*L*P and
+// L*P for separate tensors, 3*L*P for both when they are the two parts of one packed tensor
+// (row = L*P (x, y) pairs followed by L*P weights).  The location stride is even (the packed
+// form is only taken for even L*P), so that an (x, y) pair moves with one 8-byte (4-byte for
+// 16-bit types) access.
+struct PointRows {
+  int loc, attn;
+};
+
+// sampling location (x, y) and attention weight of point i of row `row`
 template <typename LT>
 __device__ __forceinline__ void load_point(const LT* __restrict__ loc, const LT* __restrict__ attn,
-                                           int64_t idx, float& x, float& y, float& a) {
+                                           int64_t row, int i, PointRows rs, float& x, float& y,
+                                           float& a) {
+  const LT* xy_p = loc + row * rs.loc + 2 * i;
   if constexpr (sizeof(LT) == 4) {
-    const float2 xy = *reinterpret_cast<const float2*>(loc + 2 * idx);
+    const float2 xy = *reinterpret_cast<const float2*>(xy_p);
     x = xy.x;
     y = xy.y;
   } else {
     LT pair[2];  // one 4-byte load for the two 16-bit coordinates
-    __builtin_memcpy(pair, loc + 2 * idx, 4);
+    __builtin_memcpy(pair, xy_p, 4);
     x = Elem<LT>::load(&pair[0]);
     y = Elem<LT>::load(&pair[1]);
   }
-  a = Elem<LT>::load(attn + idx);
+  a = Elem<LT>::load(attn + row * rs.attn + i);
 }
 
 struct EmitCtx {
@@ -301,7 +312,7 @@ __device__ __forceinline__ void stage_chunk(const LevelInfo* lv, const LT* __res
                                             const LT* __restrict__ attn, uint4* stage, int b,
                                             int q_first, int nq, int m, int M, int Lq, int LP,
                                             int P, int i_first, int nI, int LPB, uint32_t rowb,
-                                            uint32_t headb, const EmitCtx& emit) {
+                                            uint32_t headb, PointRows rs, const EmitCtx& emit) {
   // points i_first .. i_first + nI - 1 of every query; LDS lists are laid out for LPB points
   constexpr int SLOTS = stage_slots(KIND);
   const int npts = nq * nI;
@@ -313,9 +324,9 @@ __device__ __forceinline__ void stage_chunk(const LevelInfo* lv, const LT* __res
     const int i = i_first + ii;
     small_divmod(i, P, inv_P, l, p_unused);
     const LevelInfo L_ = lv[l];
-    const int64_t idx = ((static_cast<int64_t>(b) * Lq + q_first + g) * M + m) * LP + i;
+    const int64_t row = (static_cast<int64_t>(b) * Lq + q_first + g) * M + m;
     float x, y, a;
-    load_point(loc, attn, idx, x, y, a);
+    load_point(loc, attn, row, i, rs, x, y, a);
     const Footprint<float> f = footprint<float>(x, y, L_.H, L_.W);
     uint4 wrec, orec;
     wrec.x = __float_as_uint(a * f.w[0]);
@@ -366,7 +377,8 @@ template <typename VT, typename LT, int G>
 __global__ __launch_bounds__(256) void fwd_tuned_kernel(
     const VT* __restrict__ value, const int64_t* __restrict__ shapes,
     const int64_t* __restrict__ lsi, const LT* __restrict__ loc, const LT* __restrict__ attn,
-    VT* __restrict__ out, int S, int M, int Lq, int L, int P, int LPB, int head_major) {
+    VT* __restrict__ out, int S, int M, int Lq, int L, int P, int LPB, int head_major,
+    PointRows rs) {
   constexpr int CPL = Chunk<VT>::kCPL;
   constexpr int D = G * CPL;
   // one chunk per lane here: two (as in the backward query kernel) measured 20 % slower, the
@@ -406,7 +418,7 @@ __global__ __launch_bounds__(256) void fwd_tuned_kernel(
     const int nI = min(LPB, LP - ib);
     if (ib > 0) __syncthreads();
     stage_chunk<LT, kStageFwd, false>(lv, loc, attn, lds, b, q0, nq, m, M, Lq, LP, P, ib, nI, LPB,
-                                      rowb, headb, EmitCtx{});
+                                      rowb, headb, rs, EmitCtx{});
     __syncthreads();
     if (live) {
 #pragma unroll 4
@@ -507,7 +519,7 @@ __global__ __launch_bounds__(256) void bwd_query_kernel(
     const LT* __restrict__ loc, const LT* __restrict__ attn, LT* __restrict__ grad_loc,
     LT* __restrict__ grad_attn, float* __restrict__ gv_acc, uint4* __restrict__ records,
     uint2* __restrict__ dir, int S, int M, int Lq, int L, int P, int LPB, int head_major,
-    BinPlan plan) {
+    PointRows rs, BinPlan plan) {
   constexpr int CPL = Chunk<VT>::kCPL;
   constexpr int D = G * CPL;
   constexpr int GQ = query_lanes(G);  // lanes per query
@@ -552,9 +564,9 @@ __global__ __launch_bounds__(256) void bwd_query_kernel(
       small_divmod(t, LP, inv_LP, g, i);
       small_divmod(i, P, inv_P, l, p_unused);
       const LevelInfo L_ = lv[l];
-      const int64_t idx = ((static_cast<int64_t>(b) * Lq + qb0 + g) * M + m) * LP + i;
+      const int64_t row = (static_cast<int64_t>(b) * Lq + qb0 + g) * M + m;
       float x, y, a;
-      load_point(loc, attn, idx, x, y, a);
+      load_point(loc, attn, row, i, rs, x, y, a);
       const Footprint<float> f = footprint<float>(x, y, L_.H, L_.W);
       if (f.any && a != 0.f) {
         uint32_t tiles[4];
@@ -595,7 +607,7 @@ __global__ __launch_bounds__(256) void bwd_query_kernel(
     const int nq = min(GPB, qb_n - c0);
     const int nI = min(LPB, LP - ib);
     stage_chunk<LT, KIND, MODE == 1>(lv, loc, attn, stage, b, qb0 + c0, nq, m, M, Lq, LP, P, ib,
-                                     nI, LPB, rowb, headb, emit);
+                                     nI, LPB, rowb, headb, rs, emit);
     __syncthreads();
     // lanes of groups past the end redo the last group (no writes) so that every DPP row is full
     const bool live = g < nq;
@@ -680,13 +692,14 @@ __global__ __launch_bounds__(256) void bwd_query_kernel(
       }
       const int i = i0 + lane;
       if (i < nI && live && !(kAblate & 2)) {
-        const int64_t gi = triple * LP + ib + i;
-        Elem<LT>::store(grad_attn + gi, keep_sv);
+        // the gradients have the layout of their inputs (separate tensors or one packed row)
+        Elem<LT>::store(grad_attn + triple * rs.attn + ib + i, keep_sv);
+        LT* gl = grad_loc + triple * rs.loc + 2 * (ib + i);
         if constexpr (sizeof(LT) == 4) {
-          *reinterpret_cast<float2*>(grad_loc + 2 * gi) = make_float2(keep_sx, keep_sy);
+          *reinterpret_cast<float2*>(gl) = make_float2(keep_sx, keep_sy);
         } else {
-          Elem<LT>::store(grad_loc + 2 * gi, keep_sx);
-          Elem<LT>::store(grad_loc + 2 * gi + 1, keep_sy);
+          Elem<LT>::store(gl, keep_sx);
+          Elem<LT>::store(gl + 1, keep_sy);
         }
       }
     }
@@ -945,6 +958,13 @@ inline bool tuned_shape_ok(int N, int S, int M, int D, int Lq, int L, int P, int
   return true;
 }
 
+// The packed location/weight form needs rows of an even number of elements that start on a pair
+// boundary (8 bytes for fp32, 4 for 16-bit types).
+inline bool pair_aligned(const void* p, int dtype_loc) {
+  return reinterpret_cast<uintptr_t>(p) % (dtype_loc == 0 ? 8 : 4) == 0;
+}
+inline bool packed_shape_ok(int L, int P) { return (L * P) % 2 == 0; }
+
 // Points staged per pass: the largest multiple of G (lanes per query) whose LDS lists (`slots`
 // 16-byte slots per point, 256/G groups) stay within ~26 KB, or all L*P points when they fit.
 inline int stage_points_per_pass(int G, int LP, int slots) {
@@ -1048,7 +1068,9 @@ __global__ __launch_bounds__(256) void relayout_rows_kernel(const uint4* __restr
 template <typename VT, typename LT>
 int tuned_forward_typed(const void* value, const int64_t* shapes, const int64_t* lsi,
                         const void* loc, const void* attn, void* out, int N, int S, int M, int Lq,
-                        int L, int P, int G, bool head_major, hipStream_t stream) {
+                        int L, int P, int G, bool head_major, bool packed, hipStream_t stream) {
+  const PointRows rs = packed ? PointRows{3 * L * P, 3 * L * P} : PointRows{2 * L * P, L * P};
+  if (packed) attn = static_cast<const LT*>(loc) + 2 * L * P;  // the weights follow the pairs
   const int GQ = G;
   const int GPB = 256 / GQ;
   const dim3 grid(static_cast<unsigned>((Lq + GPB - 1) / GPB) * M, N);
@@ -1058,7 +1080,7 @@ int tuned_forward_typed(const void* value, const int64_t* shapes, const int64_t*
   hipLaunchKernelGGL((fwd_tuned_kernel<VT, LT, GG>), grid, dim3(256), lds, stream,              \
                      static_cast<const VT*>(value), shapes, lsi, static_cast<const LT*>(loc),   \
                      static_cast<const LT*>(attn), static_cast<VT*>(out), S, M, Lq, L, P, LPB,   \
-                     head_major ? 1 : 0)
+                     head_major ? 1 : 0, rs)
   switch (G) {
     case 4: MSDA_TF(4); break;
     case 8: MSDA_TF(8); break;
@@ -1072,11 +1094,13 @@ int tuned_forward_typed(const void* value, const int64_t* shapes, const int64_t*
 inline int tuned_forward(const void* value, const int64_t* shapes, const int64_t* lsi,
                          const void* loc, const void* attn, void* out, int N, int S, int M, int D,
                          int Lq, int L, int P, int dtype_val, int dtype_loc, bool head_major,
-                         hipStream_t stream) {
+                         bool packed, hipStream_t stream) {
   int G;
   if (!tuned_shape_ok(N, S, M, D, Lq, L, P, dtype_val, dtype_loc, &G)) return kNotTuned;
   if (!all_aligned16({value, out})) return kNotTuned;
-#define MSDA_ARGS value, shapes, lsi, loc, attn, out, N, S, M, Lq, L, P, G, head_major, stream
+  if (!pair_aligned(loc, dtype_loc) || (packed && !packed_shape_ok(L, P))) return kNotTuned;
+#define MSDA_ARGS \
+  value, shapes, lsi, loc, attn, out, N, S, M, Lq, L, P, G, head_major, packed, stream
   if (dtype_val == 0) return tuned_forward_typed<float, float>(MSDA_ARGS);
   if (dtype_val == 2)
     return dtype_loc == 0 ? tuned_forward_typed<bf16_t, float>(MSDA_ARGS)
@@ -1104,7 +1128,12 @@ int tuned_backward_typed(const void* grad_out, const void* value, const int64_t*
                          const int64_t* lsi, const void* loc, const void* attn, void* grad_value,
                          void* grad_loc, void* grad_attn, void* workspace, int N, int S, int M,
                          int D, int Lq, int L, int P, int G, bool allow_binned, bool head_major,
-                         const int64_t* levels_host, hipStream_t stream) {
+                         bool packed, const int64_t* levels_host, hipStream_t stream) {
+  const PointRows rs = packed ? PointRows{3 * L * P, 3 * L * P} : PointRows{2 * L * P, L * P};
+  if (packed) {  // the weights (and their gradient) follow the pairs inside each packed row
+    attn = static_cast<const LT*>(loc) + 2 * L * P;
+    grad_attn = static_cast<LT*>(grad_loc) + 2 * L * P;
+  }
   const int GQ = query_lanes(G);
   const int GPB = 256 / GQ;
   const int LP = L * P;
@@ -1136,7 +1165,7 @@ int tuned_backward_typed(const void* grad_out, const void* value, const int64_t*
                      lsi, static_cast<const LT*>(loc), static_cast<const LT*>(attn),             \
                      static_cast<LT*>(grad_loc), static_cast<LT*>(grad_attn),                    \
                      static_cast<float*>(nullptr), records, dir, S, M, Lq, L, P, LPB,            \
-                     head_major ? 1 : 0, plan);                                                  \
+                     head_major ? 1 : 0, rs, plan);                                              \
   hipLaunchKernelGGL((bwd_tile_gather_kernel<VT, GG, RPT>), tgrid, dim3(256), tlds, stream,      \
                      static_cast<const VT*>(grad_out), shapes, lsi, records, dir,                \
                      static_cast<VT*>(grad_value), S, M, Lq, L, plan)
@@ -1172,7 +1201,7 @@ int tuned_backward_typed(const void* grad_out, const void* value, const int64_t*
                      lsi, static_cast<const LT*>(loc), static_cast<const LT*>(attn),             \
                      static_cast<LT*>(grad_loc), static_cast<LT*>(grad_attn), acc,               \
                      static_cast<uint4*>(nullptr), static_cast<uint2*>(nullptr), S, M, Lq, L, P, \
-                     LPB, 0, plan)
+                     LPB, 0, rs, plan)
   switch (G) {
     case 4: MSDA_TB(4); break;
     case 8: MSDA_TB(8); break;
@@ -1197,14 +1226,17 @@ inline int tuned_backward(const void* grad_out, const void* value, const int64_t
                           const int64_t* lsi, const void* loc, const void* attn, void* grad_value,
                           void* grad_loc, void* grad_attn, void* workspace, int N, int S, int M,
                           int D, int Lq, int L, int P, int dtype_val, int dtype_loc,
-                          bool allow_binned, bool head_major, const int64_t* levels_host,
-                          hipStream_t stream) {
+                          bool allow_binned, bool head_major, bool packed,
+                          const int64_t* levels_host, hipStream_t stream) {
   int G;
   if (!tuned_shape_ok(N, S, M, D, Lq, L, P, dtype_val, dtype_loc, &G)) return kNotTuned;
   if (!all_aligned16({value, grad_out, grad_value, workspace})) return kNotTuned;
+  if (!pair_aligned(loc, dtype_loc) || !pair_aligned(grad_loc, dtype_loc) ||
+      (packed && !packed_shape_ok(L, P)))
+    return kNotTuned;
 #define MSDA_ARGS                                                                               \
   grad_out, value, shapes, lsi, loc, attn, grad_value, grad_loc, grad_attn, workspace, N, S, M, \
-      D, Lq, L, P, G, allow_binned, head_major, levels_host, stream
+      D, Lq, L, P, G, allow_binned, head_major, packed, levels_host, stream
   if (dtype_val == 0) return tuned_backward_typed<float, float>(MSDA_ARGS);
   if (dtype_val == 2)
     return dtype_loc == 0 ? tuned_backward_typed<bf16_t, float>(MSDA_ARGS)

@@ -102,8 +102,9 @@ class MultiScaleFlashAttnFunction(torch.autograd.Function):
     weights arrive as one tensor ``cat([loc.flatten(-3), attn.flatten(-2)], -1)`` of shape
     ``(N, Lq, M, L*P*3)``.  As in that test, the weights are used as given (the test passes
     already normalised weights and compares with ``reference.deform_attn``), i.e. no softmax is
-    applied here.  Runs the same HIP kernels as ``MultiScaleDeformAttnFunction`` after unpacking;
-    the gradient comes back packed the same way.
+    applied here.  The tuned HIP kernels read the packed tensor directly and write the gradient
+    packed the same way; shapes they do not cover (odd L*P, head dims without a tuned kernel,
+    fp64) are unpacked and go through the same path as ``MultiScaleDeformAttnFunction``.
     """
 
     @staticmethod
@@ -124,18 +125,28 @@ class MultiScaleFlashAttnFunction(torch.autograd.Function):
         n, lq, m, width = packed.shape
         points = width // (3 * levels)
         lp = levels * points
-        loc = packed[..., : 2 * lp].reshape(n, lq, m, levels, points, 2)
-        attn = packed[..., 2 * lp :].reshape(n, lq, m, levels, points)
         _lib.check(
             _lib.load().msda_check_im2col_step(int(value.shape[0]), int(im2col_step)),
             "im2col_step check",
         )
+        loc = packed[..., : 2 * lp].reshape(n, lq, m, levels, points, 2)  # a view when possible
         fflags = forward_flags()
         bflags = backward_flags(value, loc)
+        ctx.direct = (
+            os.environ.get("MSDA_NO_PACKED_POINTS") != "1"
+            and not (fflags | bflags) & (_lib.FLAG_GENERIC | _lib.FLAG_DETERMINISTIC)
+            and value.is_cuda
+            and _ops.packed_points_supported(value, packed, levels)
+        )
         ctx.head_major = use_head_major(value, loc, bflags)
         if ctx.head_major:
             value = _ops.ms_deform_attn_value_head_major(value)
             fflags |= _lib.FLAG_VALUE_HEAD_MAJOR
+        if ctx.direct:
+            out = _ops.ms_flash_attn_fwd(value, spatial_shapes, level_start_index, packed, fflags)
+            ctx.save_for_backward(value, spatial_shapes, level_start_index, packed)
+            return out
+        attn = packed[..., 2 * lp :].reshape(n, lq, m, levels, points)
         out = _ops.ms_deform_attn_fwd(value, spatial_shapes, level_start_index, loc, attn, fflags)
         ctx.save_for_backward(value, spatial_shapes, level_start_index, loc, attn)
         return out
@@ -143,6 +154,18 @@ class MultiScaleFlashAttnFunction(torch.autograd.Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, grad_output: torch.Tensor):
+        if ctx.direct:
+            value, spatial_shapes, level_start_index, packed = ctx.saved_tensors
+            levels = int(spatial_shapes.shape[0])
+            lp = packed.shape[-1] // 3
+            loc_view = packed[..., : 2 * lp].unflatten(-1, (levels, lp // levels, 2))
+            flags = backward_flags(value, loc_view)
+            if ctx.head_major:
+                flags |= _lib.FLAG_VALUE_HEAD_MAJOR
+            grad_value, grad_packed = _ops.ms_flash_attn_bwd(
+                grad_output, value, spatial_shapes, level_start_index, packed, flags
+            )
+            return grad_value, None, None, grad_packed, None
         value, spatial_shapes, level_start_index, loc, attn = ctx.saved_tensors
         flags = backward_flags(value, loc)
         if ctx.head_major:

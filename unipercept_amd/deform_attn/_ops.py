@@ -212,6 +212,141 @@ def _(grad_output, value, spatial_shapes, level_start_index, sampling_locations,
     )
 
 
+def _packed_dims(value, packed, levels: int, head_major: bool):
+    if head_major:
+        n, m, s, d = value.shape
+    else:
+        n, s, m, d = value.shape
+    lq = packed.shape[1]
+    p = packed.shape[3] // (3 * levels)
+    return n, s, m, d, lq, levels, p
+
+
+def _prepare_packed(value, shapes, lsi, packed, head_major: bool):
+    """Packed-points counterpart of `_prepare`: packed is (N, Lq, M, 3*L*P), per row the L*P
+    (x, y) pairs followed by the L*P weights."""
+    levels = int(shapes.shape[0])
+    if value.dim() != 4 or packed.dim() != 4 or packed.shape[-1] % (3 * levels) != 0:
+        raise ValueError(
+            f"expected value (N,S,M,D) and packed locations+weights (N,Lq,M,L*P*3) with L = "
+            f"{levels}; got {tuple(value.shape)}, {tuple(packed.shape)}"
+        )
+    n, s, m, d, lq, l, p = _packed_dims(value, packed, levels, head_major)
+    if packed.shape[0] != n or packed.shape[2] != m or p < 1:
+        raise ValueError(f"inconsistent shapes: value {tuple(value.shape)}, packed {tuple(packed.shape)}")
+    if tuple(shapes.shape) != (l, 2) or tuple(lsi.shape) != (l,):
+        raise ValueError(f"spatial_shapes must be ({l}, 2) and level_start_index ({l},)")
+    if value.dtype not in _DTYPE_CODE:
+        raise TypeError(f"unsupported value dtype {value.dtype}")
+    if value.device.type != "cuda" or packed.device != value.device:
+        raise RuntimeError("ms_flash_attn runs only on a ROCm GPU, with all tensors on one device")
+    dev = value.device
+    shapes_in, lsi_in = shapes, lsi
+    shapes = shapes.to(device=dev, dtype=torch.int64).contiguous()
+    lsi = lsi.to(device=dev, dtype=torch.int64).contiguous()
+    vdt = value.dtype
+    ldt = torch.float32 if packed.dtype == torch.float32 and vdt in (torch.bfloat16, torch.float16) else vdt
+    packed = packed.to(ldt).contiguous()
+    value = value.contiguous()
+    levels_host = _check_levels(shapes_in, lsi_in, shapes, lsi, s)
+    return value, shapes, lsi, packed, levels_host
+
+
+@torch.library.custom_op("unipercept::ms_flash_attn_fwd", mutates_args=())
+def ms_flash_attn_fwd(
+    value: torch.Tensor,
+    spatial_shapes: torch.Tensor,
+    level_start_index: torch.Tensor,
+    packed: torch.Tensor,
+    flags: int,
+) -> torch.Tensor:
+    """Forward on the packed locations+weights tensor itself (no unpacking pass)."""
+    lib = _lib.load()
+    hm = bool(flags & _lib.FLAG_VALUE_HEAD_MAJOR)
+    value, shapes, lsi, packed, _ = _prepare_packed(
+        value, spatial_shapes, level_start_index, packed, hm
+    )
+    n, s, m, d, lq, l, p = _packed_dims(value, packed, int(shapes.shape[0]), hm)
+    out = torch.empty((n, lq, m * d), dtype=value.dtype, device=value.device)
+    with torch.cuda.device_of(value):
+        rc = lib.msda_forward(
+            value.data_ptr(), shapes.data_ptr(), lsi.data_ptr(), packed.data_ptr(), None,
+            out.data_ptr(), n, s, m, d, lq, l, p, _DTYPE_CODE[value.dtype],
+            _DTYPE_CODE[packed.dtype], flags | _lib.FLAG_PACKED_POINTS, _stream_ptr(value.device),
+        )
+    _lib.check(rc, "msda_forward (packed points)")
+    return out
+
+
+@ms_flash_attn_fwd.register_fake
+def _(value, spatial_shapes, level_start_index, packed, flags):
+    d = value.shape[3]
+    return value.new_empty((packed.shape[0], packed.shape[1], packed.shape[2] * d))
+
+
+@torch.library.custom_op("unipercept::ms_flash_attn_bwd", mutates_args=())
+def ms_flash_attn_bwd(
+    grad_output: torch.Tensor,
+    value: torch.Tensor,
+    spatial_shapes: torch.Tensor,
+    level_start_index: torch.Tensor,
+    packed: torch.Tensor,
+    flags: int,
+) -> tuple[torch.Tensor, torch.Tensor]:
+    """Backward on the packed tensor: returns grad_value (N,S,M,D) and the packed gradient."""
+    lib = _lib.load()
+    packed_dtype = packed.dtype
+    hm = bool(flags & _lib.FLAG_VALUE_HEAD_MAJOR)
+    value, shapes, lsi, packed, levels_host = _prepare_packed(
+        value, spatial_shapes, level_start_index, packed, hm
+    )
+    n, s, m, d, lq, l, p = _packed_dims(value, packed, int(shapes.shape[0]), hm)
+    grad_output = grad_output.to(value.dtype).contiguous()
+    if tuple(grad_output.shape) != (n, lq, m * d):
+        raise ValueError(f"grad_output must be {(n, lq, m * d)}, got {tuple(grad_output.shape)}")
+    grad_value = torch.empty((n, s, m, d), dtype=value.dtype, device=value.device)
+    grad_packed = torch.empty_like(packed)
+    vcode, lcode = _DTYPE_CODE[value.dtype], _DTYPE_CODE[packed.dtype]
+    flags |= _lib.FLAG_PACKED_POINTS
+    with torch.cuda.device_of(value):
+        nbytes = lib.msda_backward_workspace_bytes(
+            n, s, m, d, lq, l, p, vcode, lcode, flags, levels_host
+        )
+        workspace = (
+            torch.empty(nbytes, dtype=torch.uint8, device=value.device) if nbytes else None
+        )
+        rc = lib.msda_backward(
+            grad_output.data_ptr(), value.data_ptr(), shapes.data_ptr(), lsi.data_ptr(),
+            packed.data_ptr(), None, grad_value.data_ptr(), grad_packed.data_ptr(), None,
+            workspace.data_ptr() if nbytes else None, nbytes,
+            n, s, m, d, lq, l, p, vcode, lcode, flags, levels_host, _stream_ptr(value.device),
+        )
+    _lib.check(rc, "msda_backward (packed points)")
+    return grad_value, grad_packed.to(packed_dtype)
+
+
+@ms_flash_attn_bwd.register_fake
+def _(grad_output, value, spatial_shapes, level_start_index, packed, flags):
+    gv = value.transpose(1, 2) if flags & _lib.FLAG_VALUE_HEAD_MAJOR else value
+    return torch.empty_like(gv, memory_format=torch.contiguous_format), torch.empty_like(packed)
+
+
+def packed_points_supported(value: torch.Tensor, packed: torch.Tensor, levels: int) -> bool:
+    """Whether the kernels read this packed locations+weights tensor directly."""
+    if value.dtype not in _DTYPE_CODE or value.dim() != 4 or packed.dim() != 4:
+        return False
+    if levels < 1 or packed.shape[-1] % (3 * levels) != 0:
+        return False
+    n, s, m, d, lq, l, p = _packed_dims(value, packed, levels, False)
+    vdt = value.dtype
+    ldt = torch.float32 if packed.dtype == torch.float32 and vdt in (torch.bfloat16, torch.float16) else vdt
+    return bool(
+        _lib.load().msda_packed_points_supported(
+            n, s, m, d, lq, l, p, _DTYPE_CODE[vdt], _DTYPE_CODE[ldt]
+        )
+    )
+
+
 @torch.library.custom_op("unipercept::ms_deform_attn_value_head_major", mutates_args=())
 def ms_deform_attn_value_head_major(value: torch.Tensor) -> torch.Tensor:
     """(N,S,M,D) -> a new contiguous (N,M,S,D) tensor (one slab per head), by a HIP row copy."""
