@@ -161,6 +161,34 @@ int msda_backward(const void* grad_out, const void* value, const int64_t* shapes
                   int S, int M, int D, int Lq, int L, int P, int dtype_val, int dtype_loc,
                   int flags, const int64_t* shapes_host, void* hip_stream);
 
+/*
+ * Sampling-point epilogue of the layer that calls the op.  `raw` (N, Lq, M, 3*L*P) is the output
+ * of ONE projection that computes sampling offsets and attention logits together, laid out per
+ * (batch, query, head) row as L*P (dx, dy) offsets followed by L*P logits; `ref_points`
+ * (N, Lq, L, 2) holds the query's reference point on every level.  Writes the packed
+ * locations+weights tensor that MSDA_FLAG_PACKED_POINTS takes:
+ *     (x, y) = ref + (dx / W_l, dy / H_l),   weights = softmax over the L*P logits of the row.
+ * One pass over the tensor instead of the softmax / divide / add / concatenate sequence of the
+ * canonical layer.  The reference's own layer body is absent from the snapshot (its package
+ * `unipercept.nn.layers.deform_attn` is imported at
+ * tests/unipercept/nn/layers/test_nn_layers_deform_attn.py:6-10 only); this follows the
+ * Deformable-DETR / Mask2Former pixel-decoder convention its models use.  All tensors have
+ * `dtype` (F32, BF16 or F16); `raw` and `packed` must be 16-byte aligned and may not overlap.
+ */
+int msda_points_forward(const void* raw, const void* ref_points, const int64_t* shapes_dev,
+                        void* packed, int N, int Lq, int M, int L, int P, int dtype,
+                        void* hip_stream);
+
+/*
+ * Gradient of msda_points_forward with respect to `raw`, from the gradient of `packed` and
+ * `packed` itself (its weights part):  d(dx, dy) = d(x, y) / (W_l, H_l),
+ * d logit_i = w_i * (g_i - sum_k w_k g_k).  The gradient of `ref_points`, where a caller needs
+ * it, is the sum of d(x, y) over heads and points.
+ */
+int msda_points_backward(const void* grad_packed, const void* packed, const int64_t* shapes_dev,
+                         void* grad_raw, int N, int Lq, int M, int L, int P, int dtype,
+                         void* hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

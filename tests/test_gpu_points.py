@@ -1,0 +1,104 @@
+"""Sampling-point epilogue (raw offsets + logits -> packed locations + softmax weights) and the
+layer path built on it, against the plain PyTorch formulation of the canonical layer."""
+
+from __future__ import annotations
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _torch_points(raw, ref, shapes):
+    """The unfused sequence: softmax over the logits, offsets / (W, H) + reference point, concat."""
+    n, lq, m, width = raw.shape
+    levels = shapes.shape[0]
+    lp = width // 3
+    off = raw[..., : 2 * lp].reshape(n, lq, m, levels, lp // levels, 2)
+    wh = torch.stack((shapes[:, 1], shapes[:, 0]), -1).to(raw.dtype)
+    loc = ref[:, :, None, :, None, :] + off / wh[None, None, None, :, None, :]
+    attn = raw[..., 2 * lp :].softmax(-1)
+    return torch.cat((loc.flatten(-3), attn), dim=-1)
+
+
+CASES = {
+    # name: (n, lq, m, levels, p)
+    "enc_L3P4": (2, 700, 8, [(32, 64), (16, 32), (8, 16)], 4),
+    "L4P8": (1, 333, 8, [(16, 32), (8, 16), (4, 8), (2, 4)], 8),
+    "odd_L3P3": (1, 515, 5, [(17, 23), (9, 12), (1, 7)], 3),
+    "one_row": (1, 1, 1, [(4, 4)], 1),
+}
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("case", sorted(CASES))
+def test_points_forward_backward_match_torch(case, dtype):
+    from unipercept_amd.deform_attn import SamplingPointsFunction
+
+    n, lq, m, levels, p = CASES[case]
+    g = torch.Generator(device="cuda").manual_seed(7)
+    shapes = torch.as_tensor(levels, dtype=torch.long, device="cuda")
+    l = len(levels)
+    raw = (torch.randn(n, lq, m, 3 * l * p, generator=g, device="cuda") * 3).to(dtype)
+    ref = torch.rand(n, lq, l, 2, generator=g, device="cuda").to(dtype)
+    grad = torch.randn(n, lq, m, 3 * l * p, generator=g, device="cuda").to(dtype)
+
+    raw_a = raw.clone().requires_grad_(True)
+    ref_a = ref.clone().requires_grad_(True)
+    got = SamplingPointsFunction.apply(raw_a, ref_a, shapes)
+    got.backward(grad)
+
+    # reference in fp64 from the same (rounded) inputs
+    raw_b = raw.double().requires_grad_(True)
+    ref_b = ref.double().requires_grad_(True)
+    want = _torch_points(raw_b, ref_b, shapes)
+    want.backward(grad.double())
+
+    # fp32: a few ulp (1/W by multiplication, expf); 16-bit: one rounding of the result
+    rel = {torch.float32: 2e-6, torch.bfloat16: 2**-8, torch.float16: 2**-10}[dtype]
+    for name, a, b in (
+        ("packed", got, want), ("grad_raw", raw_a.grad, raw_b.grad), ("grad_ref", ref_a.grad, ref_b.grad)
+    ):
+        err = (a.double() - b).abs().max().item()
+        scale = b.abs().max().item() + 1e-30
+        if name == "grad_ref" and dtype != torch.float32:
+            # a sum of M*P rounded terms
+            assert err / scale <= rel * 8, (name, err, scale)
+        elif name == "grad_raw" and dtype != torch.float32:
+            # the backward reads the softmax weights as the forward stored them (rounded to the
+            # 16-bit type) and rounds its own result: two roundings
+            assert err / scale <= rel * 2, (name, err, scale)
+        else:
+            assert err / scale <= rel, (name, err, scale)
+
+
+def test_fused_layer_matches_unfused():
+    """MSDeformAttn with the single projection + point epilogue + packed kernels gives the same
+    output and parameter gradients as the separate-projection route."""
+    from unipercept_amd.deform_attn import MSDeformAttn
+
+    torch.manual_seed(3)
+    levels = [(32, 64), (16, 32), (8, 16)]
+    shapes = torch.as_tensor(levels, dtype=torch.long, device="cuda")
+    lsi = torch.cat((shapes.new_zeros((1,)), shapes.prod(1).cumsum(0)[:-1]))
+    s = int(shapes.prod(1).sum())
+    layer = MSDeformAttn(d_model=256, n_levels=3, n_heads=8, n_points=4).cuda()
+    torch.nn.init.normal_(layer.sampling_offsets.weight, std=0.02)
+    torch.nn.init.normal_(layer.attention_weights.weight, std=0.05)
+    feats = torch.randn(2, s, 256, device="cuda")
+    ref = torch.rand(2, s, 3, 2, device="cuda")
+    target = torch.randn(2, s, 256, device="cuda")
+
+    def run(fused: bool):
+        layer.fused_points = fused
+        layer.zero_grad()
+        x = feats.clone().requires_grad_(True)
+        assert layer.can_fuse_points(x, ref, layer.project_value(x)) == fused
+        out = layer(x, ref, x, shapes, lsi)
+        (out * target).sum().backward()
+        return [out.detach(), x.grad] + [p.grad.clone() for p in layer.parameters()]
+
+    a, b = run(True), run(False)
+    for x, y in zip(a, b):
+        scale = y.abs().max().item() + 1e-30
+        assert (x - y).abs().max().item() / scale <= 2e-4

@@ -31,6 +31,8 @@ EXPORTS = (
     "msda_value_relayout",
     "msda_backward_workspace_bytes",
     "msda_backward",
+    "msda_points_forward",
+    "msda_points_backward",
 )
 
 _lock = threading.Lock()
@@ -63,6 +65,12 @@ def _declare(lib: ctypes.CDLL) -> None:
     lib.msda_backward.argtypes = (
         [c_vp] * 10 + [c_sz] + [c_int] * 7 + [c_int, c_int, c_int, c_vp, c_vp]
     )
+
+
+    lib.msda_points_forward.restype = c_int
+    lib.msda_points_forward.argtypes = [c_vp] * 4 + [c_int] * 6 + [c_vp]
+    lib.msda_points_backward.restype = c_int
+    lib.msda_points_backward.argtypes = [c_vp] * 4 + [c_int] * 6 + [c_vp]
 
 
 def load() -> ctypes.CDLL:

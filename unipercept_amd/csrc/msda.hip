@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include "msda_generic.h"
+#include "msda_points.h"
 #include "msda_tuned.h"
 
 namespace {
@@ -299,6 +300,66 @@ int msda_backward(const void* grad_out, const void* value, const int64_t* shapes
   }
 #undef MSDA_BWD
   return MSDA_EDTYPE;
+}
+
+int msda_points_forward(const void* raw, const void* ref_points, const int64_t* shapes_dev,
+                        void* packed, int N, int Lq, int M, int L, int P, int dtype,
+                        void* hip_stream) {
+  if (!raw || !ref_points || !shapes_dev || !packed) return MSDA_ENULL;
+  if (N < 1 || Lq < 1 || M < 1) return MSDA_ESHAPE;
+  if (L < 1 || P < 1 || L > 16 || L * P > 128) return MSDA_ELEVELS;
+  if (dtype != MSDA_F32 && dtype != MSDA_BF16 && dtype != MSDA_F16) return MSDA_EDTYPE;
+  if (!aligned(raw, 16) || !aligned(packed, 16) || !aligned(ref_points, elem_size(dtype)) ||
+      !aligned(shapes_dev, 8))
+    return MSDA_EALIGN;
+  const int64_t rows = static_cast<int64_t>(N) * Lq * M;
+  const int rpb = point_rows_per_block(L, P, false);
+  const int64_t blocks = (rows + rpb - 1) / rpb;
+  if (blocks > INT32_MAX) return MSDA_ESHAPE;
+  const size_t lds = points_lds_bytes(L, P, rpb, false);
+  hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+#define MSDA_PF(LT)                                                                           \
+  hipLaunchKernelGGL((points_forward_kernel<LT>), dim3(static_cast<unsigned>(blocks)),        \
+                     dim3(256), lds, stream, static_cast<const LT*>(raw),                     \
+                     static_cast<const LT*>(ref_points), shapes_dev, static_cast<LT*>(packed), \
+                     rows, M, L, P, rpb)
+  switch (dtype) {
+    case MSDA_F32: MSDA_PF(float); break;
+    case MSDA_BF16: MSDA_PF(bf16_t); break;
+    default: MSDA_PF(f16_t); break;
+  }
+#undef MSDA_PF
+  return launch_status();
+}
+
+int msda_points_backward(const void* grad_packed, const void* packed, const int64_t* shapes_dev,
+                         void* grad_raw, int N, int Lq, int M, int L, int P, int dtype,
+                         void* hip_stream) {
+  if (!grad_packed || !packed || !shapes_dev || !grad_raw) return MSDA_ENULL;
+  if (N < 1 || Lq < 1 || M < 1) return MSDA_ESHAPE;
+  if (L < 1 || P < 1 || L > 16 || L * P > 128) return MSDA_ELEVELS;
+  if (dtype != MSDA_F32 && dtype != MSDA_BF16 && dtype != MSDA_F16) return MSDA_EDTYPE;
+  if (!aligned(grad_packed, 16) || !aligned(packed, 16) || !aligned(grad_raw, 16) ||
+      !aligned(shapes_dev, 8))
+    return MSDA_EALIGN;
+  const int64_t rows = static_cast<int64_t>(N) * Lq * M;
+  const int rpb = point_rows_per_block(L, P, true);
+  const int64_t blocks = (rows + rpb - 1) / rpb;
+  if (blocks > INT32_MAX) return MSDA_ESHAPE;
+  const size_t lds = points_lds_bytes(L, P, rpb, true);
+  hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+#define MSDA_PB(LT)                                                                            \
+  hipLaunchKernelGGL((points_backward_kernel<LT>), dim3(static_cast<unsigned>(blocks)),        \
+                     dim3(256), lds, stream, static_cast<const LT*>(grad_packed),              \
+                     static_cast<const LT*>(packed), shapes_dev, static_cast<LT*>(grad_raw),   \
+                     rows, L, P, rpb)
+  switch (dtype) {
+    case MSDA_F32: MSDA_PB(float); break;
+    case MSDA_BF16: MSDA_PB(bf16_t); break;
+    default: MSDA_PB(f16_t); break;
+  }
+#undef MSDA_PB
+  return launch_status();
 }
 
 }  // extern "C"

@@ -2,17 +2,24 @@
 
 Exports what the reference's test imports from that package
 (tests/unipercept/nn/layers/test_nn_layers_deform_attn.py:6-10): ``MultiScaleDeformAttnFunction``,
-``MultiScaleFlashAttnFunction`` and ``reference``; plus the functional alias ``ms_deform_attn`` and the ``MSDeformAttn`` layer.
+``MultiScaleFlashAttnFunction`` and ``reference``; plus the functional alias ``ms_deform_attn``, the
+``MSDeformAttn`` layer and ``SamplingPointsFunction`` (the layer's fused point epilogue).
 """
 
 from . import reference
-from ._function import MultiScaleDeformAttnFunction, MultiScaleFlashAttnFunction, ms_deform_attn
+from ._function import (
+    MultiScaleDeformAttnFunction,
+    MultiScaleFlashAttnFunction,
+    SamplingPointsFunction,
+    ms_deform_attn,
+)
 from .layer import MSDeformAttn
 
 __all__ = [
     "MSDeformAttn",
     "MultiScaleDeformAttnFunction",
     "MultiScaleFlashAttnFunction",
+    "SamplingPointsFunction",
     "ms_deform_attn",
     "reference",
 ]

@@ -177,6 +177,35 @@ class MultiScaleFlashAttnFunction(torch.autograd.Function):
         return grad_value, None, None, grad_packed, None
 
 
+class SamplingPointsFunction(torch.autograd.Function):
+    """``packed = points(raw, reference_points, spatial_shapes)``: raw (N, Lq, M, 3*L*P) holds per
+    (batch, query, head) row the L*P (dx, dy) offsets and then the L*P attention logits of ONE
+    fused projection; the result is the packed tensor ``MultiScaleFlashAttnFunction`` takes:
+    locations ``ref + offset / (W_l, H_l)`` and softmax weights.  One HIP pass each way."""
+
+    @staticmethod
+    def forward(ctx, raw, reference_points, spatial_shapes):
+        packed = _ops.ms_deform_points_fwd(raw, reference_points, spatial_shapes)
+        ctx.save_for_backward(packed, spatial_shapes)
+        ctx.ref_needs_grad = reference_points.requires_grad
+        ctx.ref_dtype = reference_points.dtype
+        return packed
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_packed):
+        packed, spatial_shapes = ctx.saved_tensors
+        grad_raw = _ops.ms_deform_points_bwd(grad_packed, packed, spatial_shapes)
+        grad_ref = None
+        if ctx.ref_needs_grad:
+            n, lq, m, width = packed.shape
+            levels = int(spatial_shapes.shape[0])
+            lp = width // 3
+            g = grad_packed[..., : 2 * lp].reshape(n, lq, m, levels, lp // levels, 2)
+            grad_ref = g.sum(dim=(2, 4)).to(ctx.ref_dtype)
+        return grad_raw, grad_ref, None
+
+
 def ms_deform_attn(
     value: torch.Tensor,
     spatial_shapes: torch.Tensor,

@@ -347,6 +347,81 @@ def packed_points_supported(value: torch.Tensor, packed: torch.Tensor, levels: i
     )
 
 
+_POINT_DTYPES = (torch.float32, torch.bfloat16, torch.float16)
+
+
+def _points_dims(raw: torch.Tensor, shapes: torch.Tensor):
+    levels = int(shapes.shape[0])
+    if raw.dim() != 4 or levels < 1 or raw.shape[-1] % (3 * levels) != 0:
+        raise ValueError(
+            f"expected raw offsets+logits (N, Lq, M, 3*L*P) with L = {levels}; got {tuple(raw.shape)}"
+        )
+    n, lq, m, width = raw.shape
+    return n, lq, m, levels, width // (3 * levels)
+
+
+@torch.library.custom_op("unipercept::ms_deform_points_fwd", mutates_args=())
+def ms_deform_points_fwd(
+    raw: torch.Tensor, reference_points: torch.Tensor, spatial_shapes: torch.Tensor
+) -> torch.Tensor:
+    """Raw (dx, dy) offsets + attention logits -> packed locations + softmax weights, one pass."""
+    lib = _lib.load()
+    n, lq, m, l, p = _points_dims(raw, spatial_shapes)
+    if raw.dtype not in _POINT_DTYPES:
+        raise TypeError(f"unsupported dtype {raw.dtype}")
+    if raw.device.type != "cuda":
+        raise RuntimeError("ms_deform_points runs only on a ROCm GPU")
+    if tuple(reference_points.shape) != (n, lq, l, 2):
+        raise ValueError(
+            f"reference_points must be {(n, lq, l, 2)}, got {tuple(reference_points.shape)}"
+        )
+    raw = raw.contiguous()
+    ref = reference_points.to(device=raw.device, dtype=raw.dtype).contiguous()
+    shapes = spatial_shapes.to(device=raw.device, dtype=torch.int64).contiguous()
+    packed = torch.empty_like(raw)
+    with torch.cuda.device_of(raw):
+        rc = lib.msda_points_forward(
+            raw.data_ptr(), ref.data_ptr(), shapes.data_ptr(), packed.data_ptr(), n, lq, m, l, p,
+            _DTYPE_CODE[raw.dtype], _stream_ptr(raw.device),
+        )
+    _lib.check(rc, "msda_points_forward")
+    return packed
+
+
+@ms_deform_points_fwd.register_fake
+def _(raw, reference_points, spatial_shapes):
+    return torch.empty_like(raw, memory_format=torch.contiguous_format)
+
+
+@torch.library.custom_op("unipercept::ms_deform_points_bwd", mutates_args=())
+def ms_deform_points_bwd(
+    grad_packed: torch.Tensor, packed: torch.Tensor, spatial_shapes: torch.Tensor
+) -> torch.Tensor:
+    """Gradient of ms_deform_points_fwd with respect to its raw input."""
+    lib = _lib.load()
+    n, lq, m, l, p = _points_dims(packed, spatial_shapes)
+    if packed.device.type != "cuda" or grad_packed.device != packed.device:
+        raise RuntimeError("ms_deform_points runs only on a ROCm GPU")
+    packed = packed.contiguous()
+    grad_packed = grad_packed.to(packed.dtype).contiguous()
+    if grad_packed.shape != packed.shape:
+        raise ValueError(f"grad must be {tuple(packed.shape)}, got {tuple(grad_packed.shape)}")
+    shapes = spatial_shapes.to(device=packed.device, dtype=torch.int64).contiguous()
+    grad_raw = torch.empty_like(packed)
+    with torch.cuda.device_of(packed):
+        rc = lib.msda_points_backward(
+            grad_packed.data_ptr(), packed.data_ptr(), shapes.data_ptr(), grad_raw.data_ptr(),
+            n, lq, m, l, p, _DTYPE_CODE[packed.dtype], _stream_ptr(packed.device),
+        )
+    _lib.check(rc, "msda_points_backward")
+    return grad_raw
+
+
+@ms_deform_points_bwd.register_fake
+def _(grad_packed, packed, spatial_shapes):
+    return torch.empty_like(packed, memory_format=torch.contiguous_format)
+
+
 @torch.library.custom_op("unipercept::ms_deform_attn_value_head_major", mutates_args=())
 def ms_deform_attn_value_head_major(value: torch.Tensor) -> torch.Tensor:
     """(N,S,M,D) -> a new contiguous (N,M,S,D) tensor (one slab per head), by a HIP row copy."""

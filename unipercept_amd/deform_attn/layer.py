@@ -13,7 +13,12 @@ import math
 import torch
 from torch import nn
 
-from ._function import MultiScaleDeformAttnFunction
+from . import _ops
+from ._function import (
+    MultiScaleDeformAttnFunction,
+    MultiScaleFlashAttnFunction,
+    SamplingPointsFunction,
+)
 
 
 class MSDeformAttn(nn.Module):
@@ -24,6 +29,7 @@ class MSDeformAttn(nn.Module):
         n_heads: int = 8,
         n_points: int = 4,
         im2col_step: int = 64,
+        fused_points: bool = True,
     ):
         super().__init__()
         if d_model % n_heads != 0:
@@ -33,6 +39,11 @@ class MSDeformAttn(nn.Module):
         self.n_heads = n_heads
         self.n_points = n_points
         self.im2col_step = im2col_step
+        # One projection for offsets and logits + one HIP pass for softmax / reference-point
+        # arithmetic + the packed-points kernels, where the shapes allow it (2-d reference
+        # points on a ROCm device, even L*P, tuned head dim); the parameters stay the two
+        # Linear modules of the canonical layer, so state dicts are unchanged.
+        self.fused_points = fused_points
 
         self.sampling_offsets = nn.Linear(d_model, n_heads * n_levels * n_points * 2)
         self.attention_weights = nn.Linear(d_model, n_heads * n_levels * n_points)
@@ -59,21 +70,10 @@ class MSDeformAttn(nn.Module):
         nn.init.xavier_uniform_(self.output_proj.weight)
         nn.init.zeros_(self.output_proj.bias)
 
-    def sampling_inputs(
-        self,
-        query: torch.Tensor,
-        reference_points: torch.Tensor,
-        input_flatten: torch.Tensor,
-        input_spatial_shapes: torch.Tensor,
-        input_padding_mask: torch.Tensor | None = None,
-    ):
-        """Projections and reference-point arithmetic: returns (value, locations, weights)."""
+    def sampling_points(self, query, reference_points, input_spatial_shapes):
+        """Offsets / logits projections and reference-point arithmetic in plain PyTorch:
+        returns (locations (N,Lq,M,L,P,2), weights (N,Lq,M,L,P))."""
         n, lq, _ = query.shape
-        _, s, _ = input_flatten.shape
-        value = self.value_proj(input_flatten)
-        if input_padding_mask is not None:
-            value = value.masked_fill(input_padding_mask[..., None], 0.0)
-        value = value.view(n, s, self.n_heads, self.d_model // self.n_heads)
         offsets = self.sampling_offsets(query).view(
             n, lq, self.n_heads, self.n_levels, self.n_points, 2
         )
@@ -95,7 +95,50 @@ class MSDeformAttn(nn.Module):
             raise ValueError(
                 f"last dim of reference_points must be 2 or 4, got {reference_points.shape[-1]}"
             )
+        return locations, weights
+
+    def sampling_inputs(
+        self,
+        query: torch.Tensor,
+        reference_points: torch.Tensor,
+        input_flatten: torch.Tensor,
+        input_spatial_shapes: torch.Tensor,
+        input_padding_mask: torch.Tensor | None = None,
+    ):
+        """Projections and reference-point arithmetic: returns (value, locations, weights)."""
+        value = self.project_value(input_flatten, input_padding_mask)
+        locations, weights = self.sampling_points(query, reference_points, input_spatial_shapes)
         return value, locations, weights
+
+    def project_value(self, input_flatten, input_padding_mask=None):
+        n, s, _ = input_flatten.shape
+        value = self.value_proj(input_flatten)
+        if input_padding_mask is not None:
+            value = value.masked_fill(input_padding_mask[..., None], 0.0)
+        return value.view(n, s, self.n_heads, self.d_model // self.n_heads)
+
+    def fused_projection(self):
+        """Weight (M*3*L*P, C) and bias of the single projection whose output rows are, per head,
+        the 2*L*P offset components followed by the L*P logits."""
+        m, lp, c = self.n_heads, self.n_levels * self.n_points, self.d_model
+        weight = torch.cat(
+            (self.sampling_offsets.weight.view(m, 2 * lp, c), self.attention_weights.weight.view(m, lp, c)),
+            dim=1,
+        ).reshape(m * 3 * lp, c)
+        bias = torch.cat(
+            (self.sampling_offsets.bias.view(m, 2 * lp), self.attention_weights.bias.view(m, lp)), dim=1
+        ).reshape(m * 3 * lp)
+        return weight, bias
+
+    def can_fuse_points(self, query, reference_points, value) -> bool:
+        if not self.fused_points or self.op != MultiScaleDeformAttnFunction.apply:  # op replaced by a caller
+            return False
+        if not query.is_cuda or reference_points.shape[-1] != 2:
+            return False
+        n, lq, _ = query.shape
+        width = 3 * self.n_levels * self.n_points
+        probe = query.new_empty((n, lq, self.n_heads, width), device="meta")
+        return _ops.packed_points_supported(value, probe, self.n_levels)
 
     def forward(
         self,
@@ -106,9 +149,17 @@ class MSDeformAttn(nn.Module):
         input_level_start_index: torch.Tensor,
         input_padding_mask: torch.Tensor | None = None,
     ) -> torch.Tensor:
-        value, locations, weights = self.sampling_inputs(
-            query, reference_points, input_flatten, input_spatial_shapes, input_padding_mask
-        )
+        value = self.project_value(input_flatten, input_padding_mask)
+        if self.can_fuse_points(query, reference_points, value):
+            n, lq, _ = query.shape
+            weight, bias = self.fused_projection()
+            raw = torch.nn.functional.linear(query, weight, bias).view(n, lq, self.n_heads, -1)
+            packed = SamplingPointsFunction.apply(raw, reference_points, input_spatial_shapes)
+            out = MultiScaleFlashAttnFunction.apply(
+                value, input_spatial_shapes, input_level_start_index, packed, self.im2col_step
+            )
+            return self.output_proj(out)
+        locations, weights = self.sampling_points(query, reference_points, input_spatial_shapes)
         out = self.op(
             value, input_spatial_shapes, input_level_start_index, locations, weights,
             self.im2col_step,
