@@ -21,9 +21,6 @@
 // of the 4 lanes that own it (no float atomics there either), then stores the tile once.
 #pragma once
 
-#ifndef MSDA_K4_PIPE
-#define MSDA_K4_PIPE 0
-#endif
 
 #include <cstdlib>
 #include <initializer_list>
@@ -731,10 +728,7 @@ __global__ __launch_bounds__(256) void bwd_tile_gather_kernel(
   constexpr int NCH = D / (PL * CPL);       // 16-byte chunks of a row per lane
   constexpr int R = 256 * RPT;              // records per round
   constexpr int ROWB = D * sizeof(VT);      // bytes of one grad_out row of one head
-#ifndef MSDA_K4_U
-#define MSDA_K4_U (NCH >= 4 ? 2 : 8 / NCH)
-#endif
-  constexpr int U = MSDA_K4_U;              // entries fetched per walk step
+  constexpr int U = NCH >= 4 ? 2 : 8 / NCH;  // entries fetched per walk step (8 row loads)
   static_assert(NCH >= 1 && NCH * PL * CPL == D, "head dim must split into 4 lanes of chunks");
   static_assert(TS == 64, "the bucket scan is one wave wide");
   extern __shared__ uint4 lds[];
@@ -854,7 +848,6 @@ __global__ __launch_bounds__(256) void bwd_tile_gather_kernel(
     // ---- D: walk the bucket of this lane group's position ----
     if (!(kAblate & 8)) {
       const uint32_t e0 = start[pg], e1 = start[pg + 1];
-      // software pipeline: the rows of step i+1 are in flight while step i is accumulated
       float w_cur[U], rv_cur[U][NCH][CPL];
       const auto fetch = [&](uint32_t e, float (&w)[U], float (&rv)[U][NCH][CPL]) {
 #pragma unroll
@@ -874,30 +867,10 @@ __global__ __launch_bounds__(256) void bwd_tile_gather_kernel(
 #pragma unroll
             for (int c = 0; c < CPL; ++c) sum[j][c] = fmaf(w[u], rv[u][j][c], sum[j][c]);
       };
-#if MSDA_K4_PIPE
-      if (e0 < e1) {
-        fetch(e0, w_cur, rv_cur);
-        for (uint32_t e = e0 + U; e < e1; e += U) {
-          float w_nxt[U], rv_nxt[U][NCH][CPL];
-          fetch(e, w_nxt, rv_nxt);
-          accumulate(w_cur, rv_cur);
-#pragma unroll
-          for (int u = 0; u < U; ++u) {
-            w_cur[u] = w_nxt[u];
-#pragma unroll
-            for (int j = 0; j < NCH; ++j)
-#pragma unroll
-              for (int c = 0; c < CPL; ++c) rv_cur[u][j][c] = rv_nxt[u][j][c];
-          }
-        }
-        accumulate(w_cur, rv_cur);
-      }
-#else
       for (uint32_t e = e0; e < e1; e += U) {
         fetch(e, w_cur, rv_cur);
         accumulate(w_cur, rv_cur);
       }
-#endif
     }
     __syncthreads();
   }
@@ -1002,7 +975,7 @@ inline bool make_bin_plan(int N, int S, int M, int D, int Lq, int L, int P,
   };
   int64_t n_tiles = (static_cast<int64_t>(S) + TS - 1) / TS;
   int tile2d = 0;
-  if (levels_host != nullptr && getenv("MSDA_EXP_TILE1D") == nullptr) {
+  if (levels_host != nullptr && getenv("MSDA_TILE_1D") == nullptr) {
     const int tw = 1 << tw_shift, th = TS >> tw_shift;
     int64_t total = 0, nt = 0;
     bool ok = true;
@@ -1153,10 +1126,7 @@ int tuned_backward_typed(const void* grad_out, const void* value, const int64_t*
                         static_cast<size_t>(plan.n_tiles) * 8;
     const dim3 tgrid(static_cast<unsigned>(plan.n_tiles) * M, N);
     const size_t TSz = static_cast<size_t>(1) << plan.ts_shift;
-#ifndef MSDA_K4_RPT
-#define MSDA_K4_RPT 4
-#endif
-    constexpr int RPT = MSDA_K4_RPT;  // records per thread and round of the gather-walk tile kernel
+    constexpr int RPT = 4;  // records per thread and round of the gather-walk tile kernel
     const size_t tlds = 4 * 256 * RPT * 8 + (2 * TSz + 1) * 4 +
                         (2 * static_cast<size_t>(plan.n_qblocks) + 1) * 4;
 #define MSDA_TB(GG)                                                                              \
