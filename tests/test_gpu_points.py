@@ -102,3 +102,39 @@ def test_fused_layer_matches_unfused():
     for x, y in zip(a, b):
         scale = y.abs().max().item() + 1e-30
         assert (x - y).abs().max().item() / scale <= 2e-4
+
+
+def test_encoder_stack_hip_matches_oracle_injected():
+    """Two encoder layers with the HIP ops (fused point path) against the same weights run on
+    the CPU with the oracle as the sampling op: outputs and all gradients."""
+    import copy
+
+    from oracle import grid_sample_ref
+    from unipercept_amd.deform_attn import MSDeformAttnEncoder, flatten_levels
+
+    torch.manual_seed(5)
+    enc = MSDeformAttnEncoder(2, d_model=64, d_ffn=128, n_levels=3, n_heads=2, n_points=4)
+    for layer in enc.layers:
+        torch.nn.init.normal_(layer.self_attn.sampling_offsets.weight, std=0.02)
+        torch.nn.init.normal_(layer.self_attn.attention_weights.weight, std=0.1)
+    cpu = copy.deepcopy(enc)
+    for layer in cpu.layers:
+        layer.self_attn.op = lambda v, sh, li, lo, a, step: grid_sample_ref.deform_attn(v, sh, lo, a)
+    enc = enc.cuda()
+    feats = [torch.randn(2, 64, 16, 24), torch.randn(2, 64, 8, 12), torch.randn(2, 64, 4, 6)]
+    target = torch.randn(2, 16 * 24 + 8 * 12 + 4 * 6, 64)
+
+    def run(model, dev):
+        model.zero_grad()
+        src, shapes, lsi, shape_list, pos = flatten_levels([f.to(dev) for f in feats], position_feats=32)
+        src.requires_grad_(True)
+        out = model(src, shapes, lsi, pos=pos, spatial_shapes_list=shape_list)
+        (out * target.to(dev)).sum().backward()
+        return [out.detach().cpu(), src.grad.cpu()] + [p.grad.cpu() for p in model.parameters()]
+
+    got, want = run(enc, "cuda"), run(cpu, "cpu")
+    assert all(l.self_attn.can_fuse_points(torch.empty(2, 5, 64, device="cuda"), torch.empty(2, 5, 3, 2),
+                                           torch.empty(2, 9, 2, 32, device="cuda")) for l in enc.layers)
+    for g, w_ in zip(got, want):
+        scale = w_.abs().max().item() + 1e-30
+        assert (g - w_).abs().max().item() / scale <= 1e-3

@@ -25,3 +25,16 @@ def timeit(n=10):
 for fused in (True, False, True, False):
     layer.fused_points = fused
     print(f"{w.name}: layer fwd+bwd, fused_points={fused}: {timeit():.3f} ms", flush=True)
+
+# the encoder stack (LAYERS layers of {MSDeformAttn, LayerNorm, FFN, LayerNorm}) on the same input
+if os.environ.get("LAYERS"):
+    from unipercept_amd.deform_attn import MSDeformAttnEncoder
+    n_layers = int(os.environ["LAYERS"])
+    enc = MSDeformAttnEncoder(n_layers, d_model=c, d_ffn=1024, n_levels=w.n_levels, n_heads=w.heads,
+                              n_points=w.points).cuda().to(dt)
+    levels = [list(x) for x in w.levels]
+    def step():
+        x = feats.detach().requires_grad_(True)
+        enc(x, shapes, lsi, spatial_shapes_list=levels).backward(g)
+    print(f"{w.name}: {n_layers}-layer encoder fwd+bwd: {timeit(5):.3f} ms "
+          f"({sum(p.numel() for p in enc.parameters())} parameters)", flush=True)

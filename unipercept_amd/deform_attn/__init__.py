@@ -13,10 +13,22 @@ from ._function import (
     SamplingPointsFunction,
     ms_deform_attn,
 )
+from .encoder import (
+    MSDeformAttnEncoder,
+    MSDeformAttnEncoderLayer,
+    encoder_reference_points,
+    flatten_levels,
+    sine_position_embedding,
+)
 from .layer import MSDeformAttn
 
 __all__ = [
     "MSDeformAttn",
+    "MSDeformAttnEncoder",
+    "MSDeformAttnEncoderLayer",
+    "encoder_reference_points",
+    "flatten_levels",
+    "sine_position_embedding",
     "MultiScaleDeformAttnFunction",
     "MultiScaleFlashAttnFunction",
     "SamplingPointsFunction",
