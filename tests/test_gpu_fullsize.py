@@ -101,3 +101,47 @@ def test_bf16_full_size_close_to_fp32():
     gv32, gl32, ga32 = bwd(g.float(), value.float(), shapes, lsi, loc.float(), attn.float(), 0)
     for got, want, tol in ((out, out32, 2**-7), (gv, gv32, 2**-7), (ga, ga32, 2**-7), (gl, gl32, 2**-6)):
         assert (got.float() - want).abs().max() <= tol * want.abs().max()
+
+
+@pytest.mark.parametrize("name,batch", FULL)
+def test_packed_points_equal_separate_tensors(name, batch):
+    """The packed locations+weights entry point reads the same numbers from another layout:
+    identical forward, gradients equal up to the order of fp32 adds in grad_value."""
+    fwd, bwd = _ops()
+    fwd_p, bwd_p = torch.ops.unipercept.ms_flash_attn_fwd, torch.ops.unipercept.ms_flash_attn_bwd
+    w = harness.WORKLOADS[name]
+    value, shapes, lsi, loc, attn, g = harness.synth_inputs(
+        w, "cuda", batch=batch, seed=41, oob_fraction=0.01
+    )
+    packed = torch.cat([loc.flatten(-3), attn.flatten(-2)], dim=-1)
+    lp2 = 2 * w.n_levels * w.points
+    assert torch.equal(fwd_p(value, shapes, lsi, packed, 0), fwd(value, shapes, lsi, loc, attn, 0))
+    gv, gl, ga = bwd(g, value, shapes, lsi, loc, attn, 0)
+    gv_p, gp = bwd_p(g, value, shapes, lsi, packed, 0)
+    assert torch.equal(gp[..., :lp2].reshape(gl.shape), gl)
+    assert torch.equal(gp[..., lp2:].reshape(ga.shape), ga)
+    assert (gv_p - gv).abs().max() <= 1e-4 * gv.abs().max()
+
+
+def test_points_epilogue_full_size():
+    """The sampling-point epilogue at the headline shapes against the PyTorch sequence."""
+    from unipercept_amd.deform_attn import _ops as ops  # noqa: F401
+
+    w = harness.WORKLOADS["cityscapes_1024x2048_fp32_b8"]
+    shapes, _ = harness.level_tensors(w, "cuda")
+    n, s, m, l, p = 2, w.positions, w.heads, w.n_levels, w.points
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    raw = torch.randn(n, s, m, 3 * l * p, generator=gen, device="cuda") * 2
+    ref = torch.rand(n, s, l, 2, generator=gen, device="cuda")
+    grad = torch.randn(n, s, m, 3 * l * p, generator=gen, device="cuda")
+    packed = torch.ops.unipercept.ms_deform_points_fwd(raw, ref, shapes)
+    grad_raw = torch.ops.unipercept.ms_deform_points_bwd(grad, packed, shapes)
+    raw_t = raw.clone().requires_grad_(True)
+    lp = l * p
+    off = raw_t[..., : 2 * lp].reshape(n, s, m, l, p, 2)
+    wh = torch.stack((shapes[:, 1], shapes[:, 0]), -1).float()
+    loc = ref[:, :, None, :, None, :] + off / wh[None, None, None, :, None, :]
+    want = torch.cat((loc.flatten(-3), raw_t[..., 2 * lp :].softmax(-1)), dim=-1)
+    want.backward(grad)
+    assert (packed - want).abs().max() <= 2e-6 * want.abs().max()
+    assert (grad_raw - raw_t.grad).abs().max() <= 1e-5 * raw_t.grad.abs().max()
