@@ -151,3 +151,35 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "LIB_PATH", tmp_path / "libmsda.so")
     with pytest.raises(_lib.MsdaLibraryError):
         _lib.load()
+
+
+def test_packed_points_flag_arguments():
+    lib = _lib.load()
+    # with the packed flag `attn` may be NULL; without it that is an error
+    dims = (1, 4, 1, 4, 2, 1, 0)  # P = 0 -> the shape check fires after the NULL check passed
+    assert lib.msda_forward(FAKE, FAKE, FAKE, FAKE, None, FAKE, *dims, 0, 0, _lib.FLAG_PACKED_POINTS, None) == -2
+    assert lib.msda_forward(FAKE, FAKE, FAKE, FAKE, None, FAKE, *dims, 0, 0, 0, None) == -1
+    ok = lib.msda_packed_points_supported
+    assert ok(8, 43008, 8, 32, 43008, 3, 4, _lib.F32, _lib.F32) == 1
+    assert ok(8, 43008, 8, 32, 43008, 3, 4, _lib.BF16, _lib.F32) == 1
+    assert ok(1, 630, 5, 16, 515, 3, 3, _lib.F32, _lib.F32) == 0  # odd L*P
+    assert ok(1, 640, 2, 30, 5, 2, 2, _lib.F32, _lib.F32) == 0  # no tuned kernel for D = 30
+    assert ok(1, 640, 2, 32, 5, 2, 2, _lib.F64, _lib.F64) == 0
+    assert ok(0, 640, 2, 32, 5, 2, 2, _lib.F32, _lib.F32) == 0
+
+
+def test_points_epilogue_argument_errors():
+    lib = _lib.load()
+
+    def fwd(raw=FAKE, ref=FAKE, shapes=FAKE, packed=FAKE, dims=(1, 5, 2, 2, 2), dtype=0):
+        return lib.msda_points_forward(raw, ref, shapes, packed, *dims, dtype, None)
+
+    def bwd(gp=FAKE, packed=FAKE, shapes=FAKE, graw=FAKE, dims=(1, 5, 2, 2, 2), dtype=0):
+        return lib.msda_points_backward(gp, packed, shapes, graw, *dims, dtype, None)
+
+    assert fwd(raw=None) == -1 and fwd(ref=None) == -1 and bwd(graw=None) == -1
+    assert fwd(dims=(0, 5, 2, 2, 2)) == -2 and bwd(dims=(1, 0, 2, 2, 2)) == -2
+    assert fwd(dims=(1, 5, 2, 17, 2)) == -7 and bwd(dims=(1, 5, 2, 8, 32)) == -7
+    assert fwd(dtype=_lib.F64) == -3 and bwd(dtype=9) == -3
+    assert fwd(raw=FAKE + 8) == -4 and bwd(graw=FAKE + 4) == -4  # 16-byte alignment
+    assert fwd(shapes=FAKE + 4) == -4
