@@ -77,7 +77,7 @@ enum {
   MSDA_FLAG_PACKED_POINTS = 16,
 };
 
-/* Library ABI version (bumped when a signature changes). */
+/* Library ABI version (bumped when a signature changes or entry points are added). */
 int msda_version(void);
 
 /* Human-readable text for a return code of this library (static storage). */
@@ -188,6 +188,45 @@ int msda_points_forward(const void* raw, const void* ref_points, const int64_t* 
 int msda_points_backward(const void* grad_packed, const void* packed, const int64_t* shapes_dev,
                          void* grad_raw, int N, int Lq, int M, int L, int P, int dtype,
                          void* hip_stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Point sampling (PointRend): the same bilinear gather on one NCHW map with border padding.
+ * --------------------------------------------------------------------------------------------- */
+
+/* interpolation modes of msda_point_sample_* */
+enum {
+  MSDA_SAMPLE_BILINEAR = 0,
+  MSDA_SAMPLE_NEAREST = 1,
+};
+
+/*
+ * out[n, c, p] = input[n, c] sampled at point_coords[n, p] = (x, y) in [0, 1]^2.  Replaces
+ * `unipercept.vision.pointrend.sample(input, point_coords, align_corners, mode=...)`
+ * (sources/unipercept/vision/pointrend.py:25-76 of the reference), i.e.
+ * grid_sample(input, 2 * point_coords - 1, mode, padding_mode="border", align_corners):
+ * pixel coordinate ((2c - 1 + 1) * size - 1) / 2 (align_corners: (2c - 1 + 1) / 2 * (size - 1)),
+ * clamped to [0, size - 1]; bilinear, or nearest with ties to even.
+ *
+ * input (N, C, H, W), coords (N, P, 2), out (N, C, P), all of `dtype` (F32, F64, BF16, F16;
+ * 16-bit types compute in fp32), contiguous.  A (N, Hg, Wg, 2) coordinate grid is the same call
+ * with P = Hg * Wg.
+ */
+int msda_point_sample_forward(const void* input, const void* coords, void* out, int N, int C,
+                              int H, int W, int P, int dtype, int mode, int align_corners,
+                              void* hip_stream);
+
+/*
+ * Gradients of msda_point_sample_forward for a given grad_out (N, C, P): grad_input (N, C, H, W)
+ * and grad_coords (N, P, 2), both fully overwritten (zeroed by the callee where it accumulates).
+ * The coordinate gradient is 0 where the border clamp acts (pixel coordinate <= 0 or
+ * >= size - 1) and for MSDA_SAMPLE_NEAREST, as in aten::grid_sampler_2d_backward, and includes
+ * the factor 2 of `2 * point_coords - 1`.  dtype F32 or F64 (a 16-bit caller converts).
+ * grad_input is accumulated with hardware float atomics: sums of more than two contributions to
+ * one pixel may differ in the last bits from run to run.
+ */
+int msda_point_sample_backward(const void* grad_out, const void* input, const void* coords,
+                               void* grad_input, void* grad_coords, int N, int C, int H, int W,
+                               int P, int dtype, int mode, int align_corners, void* hip_stream);
 
 #ifdef __cplusplus
 }

@@ -29,7 +29,13 @@ def pytest_collection_modifyitems(config, items):
 
 
 def golden_cases():
-    return sorted(p.stem for p in GOLDEN.glob("*.npz"))
+    """MSDeformAttn vectors (tests/golden/make_golden.py)."""
+    return sorted(p.stem for p in GOLDEN.glob("*.npz") if not p.stem.startswith("pointrend_"))
+
+
+def pointrend_cases():
+    """Point-sampling vectors (tests/golden/make_golden_pointrend.py)."""
+    return sorted(p.stem for p in GOLDEN.glob("pointrend_*.npz"))
 
 
 def load_golden(name: str) -> dict[str, np.ndarray]:

@@ -183,3 +183,21 @@ def test_points_epilogue_argument_errors():
     assert fwd(dtype=_lib.F64) == -3 and bwd(dtype=9) == -3
     assert fwd(raw=FAKE + 8) == -4 and bwd(graw=FAKE + 4) == -4  # 16-byte alignment
     assert fwd(shapes=FAKE + 4) == -4
+
+
+def test_point_sample_argument_errors():
+    lib = _lib.load()
+
+    def fwd(inp=FAKE, coords=FAKE, out=FAKE, dims=(1, 1, 2, 2, 3), dtype=0, mode=0):
+        return lib.msda_point_sample_forward(inp, coords, out, *dims, dtype, mode, 0, None)
+
+    def bwd(go=FAKE, inp=FAKE, coords=FAKE, gi=FAKE, gc=FAKE, dims=(1, 1, 2, 2, 3), dtype=0, mode=0):
+        return lib.msda_point_sample_backward(go, inp, coords, gi, gc, *dims, dtype, mode, 0, None)
+
+    assert fwd(inp=None) == -1 and fwd(out=None) == -1 and bwd(gc=None) == -1
+    assert fwd(dims=(0, 1, 2, 2, 3)) == -2 and bwd(dims=(1, 1, 2, 2, 0)) == -2
+    assert fwd(dims=(1, 1, 70000, 70000, 3)) == -2  # H * W over 2^31-1
+    assert fwd(dtype=9) == -3 and fwd(mode=2) == -3
+    assert bwd(dtype=_lib.BF16) == -3 and bwd(dtype=_lib.F16) == -3  # 16-bit callers convert
+    assert fwd(inp=FAKE + 2) == -4 and bwd(gi=FAKE + 2) == -4
+    assert fwd(dtype=_lib.F64, coords=FAKE + 4) == -4

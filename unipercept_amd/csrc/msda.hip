@@ -5,13 +5,14 @@
 
 #include "msda_generic.h"
 #include "msda_points.h"
+#include "msda_sample.h"
 #include "msda_tuned.h"
 
 namespace {
 
 using namespace msda;
 
-constexpr int kAbiVersion = 2;
+constexpr int kAbiVersion = 3;
 
 inline size_t elem_size(int dtype) {
   switch (dtype) {
@@ -359,6 +360,112 @@ int msda_points_backward(const void* grad_packed, const void* packed, const int6
     default: MSDA_PB(f16_t); break;
   }
 #undef MSDA_PB
+  return launch_status();
+}
+
+int msda_point_sample_forward(const void* input, const void* coords, void* out, int N, int C,
+                              int H, int W, int P, int dtype, int mode, int align_corners,
+                              void* hip_stream) {
+  if (!input || !coords || !out) return MSDA_ENULL;
+  if (N < 1 || C < 1 || H < 1 || W < 1 || P < 1) return MSDA_ESHAPE;
+  if (static_cast<int64_t>(H) * W > INT32_MAX) return MSDA_ESHAPE;
+  const size_t e = elem_size(dtype);
+  if (e == 0 || (mode != MSDA_SAMPLE_BILINEAR && mode != MSDA_SAMPLE_NEAREST)) return MSDA_EDTYPE;
+  if (!aligned(input, e) || !aligned(coords, e) || !aligned(out, e)) return MSDA_EALIGN;
+  SampleGrid g;
+  int64_t blocks;
+  if (!make_sample_grid(N, C, P, &g, &blocks)) return MSDA_ESHAPE;
+  hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+#define MSDA_SF(T)                                                                              \
+  hipLaunchKernelGGL((point_sample_fwd_kernel<T>), dim3(static_cast<unsigned>(blocks)),         \
+                     dim3(256), 0, stream, static_cast<const T*>(input),                        \
+                     static_cast<const T*>(coords), static_cast<T*>(out), C, H, W, P, g, mode,  \
+                     align_corners ? 1 : 0)
+  switch (dtype) {
+    case MSDA_F32: MSDA_SF(float); break;
+    case MSDA_F64: MSDA_SF(double); break;
+    case MSDA_BF16: MSDA_SF(bf16_t); break;
+    default: MSDA_SF(f16_t); break;
+  }
+#undef MSDA_SF
+  return launch_status();
+}
+
+int msda_point_sample_backward(const void* grad_out, const void* input, const void* coords,
+                               void* grad_input, void* grad_coords, int N, int C, int H, int W,
+                               int P, int dtype, int mode, int align_corners, void* hip_stream) {
+  if (!grad_out || !input || !coords || !grad_input || !grad_coords) return MSDA_ENULL;
+  if (N < 1 || C < 1 || H < 1 || W < 1 || P < 1) return MSDA_ESHAPE;
+  if (static_cast<int64_t>(H) * W > INT32_MAX) return MSDA_ESHAPE;
+  if ((dtype != MSDA_F32 && dtype != MSDA_F64) ||
+      (mode != MSDA_SAMPLE_BILINEAR && mode != MSDA_SAMPLE_NEAREST))
+    return MSDA_EDTYPE;
+  const size_t e = elem_size(dtype);
+  if (!aligned(grad_out, e) || !aligned(input, e) || !aligned(coords, e) ||
+      !aligned(grad_input, e) || !aligned(grad_coords, e))
+    return MSDA_EALIGN;
+  SampleGrid g;
+  int64_t blocks;
+  if (!make_sample_grid(N, C, P, &g, &blocks)) return MSDA_ESHAPE;
+  hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+  hipError_t err;
+  // grad_input: by bands of the plane held in LDS when the map allows it, else by global atomics
+  constexpr size_t kBandLds = 128 * 1024;
+  const int band_rows = sample_band_rows(H, W, kBandLds);
+  SampleGrid bg{};
+  int64_t band_blocks = 0;
+  if (band_rows > 0) {
+    bg.per = (H + band_rows - 1) / band_rows;
+    bg.cslices = C;  // one unit per plane
+    bg.cper = 1;
+    bg.units = static_cast<int64_t>(N) * C;
+    band_blocks = sample_grid_blocks(bg);
+  }
+  const bool banded = band_rows > 0 && band_blocks <= INT32_MAX;
+  if (!banded) {
+    err = hipMemsetAsync(grad_input, 0, static_cast<size_t>(N) * C * H * W * e, stream);
+    if (err != hipSuccess) return static_cast<int>(err);
+  }
+  if (g.cslices > 1) {
+    err = hipMemsetAsync(grad_coords, 0, static_cast<size_t>(N) * P * 2 * e, stream);
+    if (err != hipSuccess) return static_cast<int>(err);
+  }
+#define MSDA_SB(T, SCATTER)                                                                     \
+  hipLaunchKernelGGL((point_sample_bwd_kernel<T, SCATTER>), dim3(static_cast<unsigned>(blocks)), \
+                     dim3(256), 0, stream, static_cast<const T*>(grad_out),                     \
+                     static_cast<const T*>(input), static_cast<const T*>(coords),               \
+                     static_cast<T*>(grad_input), static_cast<T*>(grad_coords), C, H, W, P, g,  \
+                     mode, align_corners ? 1 : 0)
+#define MSDA_SBAND(T)                                                                           \
+  do {                                                                                          \
+    const size_t lds = static_cast<size_t>(band_rows) * W * sizeof(double);                     \
+    err = hipFuncSetAttribute(reinterpret_cast<const void*>(&point_sample_bwd_band_kernel<T>),  \
+                              hipFuncAttributeMaxDynamicSharedMemorySize,                       \
+                              static_cast<int>(kBandLds));                                      \
+    if (err != hipSuccess) return static_cast<int>(err);                                        \
+    hipLaunchKernelGGL((point_sample_bwd_band_kernel<T>),                                       \
+                       dim3(static_cast<unsigned>(band_blocks)), dim3(1024), lds, stream,       \
+                       static_cast<const T*>(grad_out), static_cast<const T*>(coords),          \
+                       static_cast<T*>(grad_input), C, H, W, P, bg, band_rows, mode,            \
+                       align_corners ? 1 : 0);                                                  \
+  } while (0)
+  if (dtype == MSDA_F32) {
+    if (banded) {
+      MSDA_SB(float, false);
+      MSDA_SBAND(float);
+    } else {
+      MSDA_SB(float, true);
+    }
+  } else {
+    if (banded) {
+      MSDA_SB(double, false);
+      MSDA_SBAND(double);
+    } else {
+      MSDA_SB(double, true);
+    }
+  }
+#undef MSDA_SBAND
+#undef MSDA_SB
   return launch_status();
 }
 
