@@ -247,3 +247,25 @@ def test_flat_bucket_views_parameters():
     layer.value_proj.weight.grad.fill_(2.0)
     assert float(bucket.flat.sum()) == 2.0 * layer.value_proj.weight.numel()
     assert math.isfinite(harness.roofline_fraction(1e9, 1e-3))
+
+
+def test_packaging_build_hook_is_current():
+    """`setup.py build_hip` (the packaging entry of the HIP build) compiles the same source with
+    the same flags as __graft_entry__.build_library and sees an up-to-date library as such."""
+    import importlib.util
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    import __graft_entry__ as entry
+
+    root = Path(entry.__file__).resolve().parent
+    spec = importlib.util.spec_from_file_location("_setup_under_test", root / "setup.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    out = root / "unipercept_amd" / "libmsda.so"
+    cmd = mod.hip_command(out)
+    assert cmd[1:] == [*entry.HIP_FLAGS, "-o", str(out), str(root / "unipercept_amd" / "csrc" / "msda.hip")]
+    entry.build_library()
+    r = subprocess.run([sys.executable, "setup.py", "-q", "build_hip"], cwd=root, capture_output=True, text=True)
+    assert r.returncode == 0 and "up to date" in r.stdout, r.stdout + r.stderr
