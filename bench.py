@@ -82,6 +82,10 @@ def main() -> None:
     ap.add_argument("--packed", action="store_true",
                     help="time the packed locations+weights entry point (MultiScaleFlashAttnFunction's "
                     "kernels) instead of the separate-tensor one")
+    ap.add_argument("--layer", action="store_true",
+                    help="time the whole MSDeformAttn layer (the four projections on PyTorch-ROCm GEMMs "
+                    "around the op) with its real parameter gradients in the all-reduced bucket; "
+                    "sampling locations are then the layer's own (ring-initialised offsets)")
     ap.add_argument("--no-head-major", action="store_true",
                     help="gather from the (N,S,M,D) value as given instead of a per-head copy")
     args = ap.parse_args()
@@ -149,7 +153,45 @@ def main() -> None:
     n_ev = args.steps
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(n_ev)]
 
+    layer = None
+    if args.layer:
+        from unipercept_amd.deform_attn import MSDeformAttn
+
+        if args.packed or args.fwd_only or args.no_head_major:
+            raise SystemExit("--layer does not combine with --packed / --fwd-only / --no-head-major")
+        d_model = w.heads * w.head_dim
+        torch.manual_seed(1234)  # identical parameters on every rank, as after DDP's broadcast
+        layer = MSDeformAttn(d_model, w.n_levels, w.heads, w.points).to(device, value.dtype)
+        gq = torch.Generator(device=device).manual_seed(4321 + rank)
+        query = torch.randn(batch, w.positions, d_model, generator=gq, device=device).to(value.dtype)
+        src = value.reshape(batch, w.positions, d_model)
+        ref = harness.encoder_reference_points(w, device).to(value.dtype)
+        ref = ref.view(1, w.positions, 1, 2).expand(batch, w.positions, w.n_levels, 2).contiguous()
+        bucket = harness.FlatGradBucket.for_parameters(layer.parameters())  # p.grad are views of it
+        if comm_stream is None:
+            comm_stream = torch.cuda.Stream(device)
+        del loc, attn
+
+    def layer_step(i: int | None) -> None:
+        if i is not None:
+            ev[i][0].record()
+        out = layer(query, ref, src, shapes, lsi)
+        if i is not None:
+            ev[i][1].record()
+        # the previous step's bucket must have been reduced before this backward adds into it
+        torch.cuda.current_stream(device).wait_stream(comm_stream)
+        bucket.flat.zero_()
+        out.backward(grad_out)
+        if i is not None:
+            ev[i][2].record()
+        if distributed:
+            comm_stream.wait_stream(torch.cuda.current_stream(device))
+            with torch.cuda.stream(comm_stream):
+                bucket.all_reduce()
+
     def step(i: int | None) -> None:
+        if layer is not None:
+            return layer_step(i)
         if i is not None:
             ev[i][0].record()
         v = to_head_major(value) if head_major else value
@@ -206,7 +248,7 @@ def main() -> None:
         traffic = None
         try:
             rec = json.loads((ROOT / "profiles" / "hbm_traffic.json").read_text()).get(f"{w.name}:{args.dist}")
-            if rec is not None and batch == w.batch and not args.packed:
+            if rec is not None and batch == w.batch and not args.packed and not args.layer:
                 traffic = rec[dom]
         except (OSError, ValueError, KeyError):
             traffic = None
@@ -228,7 +270,9 @@ def main() -> None:
             "data": "synthetic",
             "config": {
                 "workload": w.name,
-                "entry_point": "MultiScaleFlashAttnFunction kernels (packed locations+weights, read in place)"
+                "entry_point": "MSDeformAttn layer (projections on PyTorch-ROCm GEMMs + point epilogue + packed-points kernels)"
+                if args.layer
+                else "MultiScaleFlashAttnFunction kernels (packed locations+weights, read in place)"
                 if args.packed
                 else "MultiScaleDeformAttnFunction kernels (separate locations / weights)",
                 "levels": [list(x) for x in w.levels],
@@ -239,7 +283,7 @@ def main() -> None:
                 "global_batch": batch * world,
                 "queries": w.positions,
                 "loc_dtype": w.loc_dtype or w.dtype,
-                "location_distribution": args.dist,
+                "location_distribution": "layer (ring-initialised offsets around the pixel centres)" if args.layer else args.dist,
                 "value_gather_layout": "per-head copy (N,M,S,D), re-laid out inside the step"
                 if head_major
                 else "as given (N,S,M,D)",
@@ -252,7 +296,9 @@ def main() -> None:
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": f"msda_{dom} (all launches of the op, HIP events in the timed loop)",
+                "kernel": f"MSDeformAttn layer {dom} (projection GEMMs included in the time; algorithmic bytes of the op alone)"
+                if args.layer
+                else f"msda_{dom} (all launches of the op, HIP events in the timed loop)",
                 "achieved": achieved,
                 "peak": HBM_PEAK / 1e9,
                 "unit": "GB/s",
