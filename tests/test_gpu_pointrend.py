@@ -108,7 +108,10 @@ def test_reference_test_importance():
 
 @pytest.mark.parametrize("mode", ["bilinear", "nearest"])
 @pytest.mark.parametrize("align", [False, True])
-@pytest.mark.parametrize("shape", [(3, 1, 37, 53, 1000), (2, 19, 16, 24, 300), (1, 70, 9, 5, 33)])
+# the last shape is too wide for the LDS bands of the grad_input kernel: global-atomic fallback
+@pytest.mark.parametrize(
+    "shape", [(3, 1, 37, 53, 1000), (2, 19, 16, 24, 300), (1, 70, 9, 5, 33), (1, 2, 3, 9000, 700)]
+)
 def test_against_oracle_f32_inputs(shape, align, mode):
     """Mid-size cases against the scalar C oracle in fp64 on the same (fp32-representable)
     inputs, points up to 20 % outside the map on every side; channel counts that split into
@@ -131,12 +134,15 @@ def test_against_oracle_f32_inputs(shape, align, mode):
         assert same.mean() > 0.995
         assert not gc.any()
         return
-    assert np.abs(out - want).max() <= FWD_ATOL_F32
-    assert np.abs(gi - wgi).max() <= BWD_ATOL_F32
+    # an fp32 pixel coordinate resolves 2^-24 of the map size: on the 9000-pixel-wide map the
+    # interpolation fraction itself is only good to ~5e-4, whatever the implementation
+    coarse = max(1.0, max(h, w) / 512.0)
+    assert np.abs(out - want).max() <= FWD_ATOL_F32 * coarse
+    assert np.abs(gi - wgi).max() <= BWD_ATOL_F32 * coarse
     # the clamp decides on the fp32 coordinate: compare away from the exact border
-    inside = (np.abs(gc - wgc) <= BWD_ATOL_F32 * max(h, w)) | (gc == 0) | (wgc == 0)
+    inside = (np.abs(gc - wgc) <= BWD_ATOL_F32 * max(h, w) * coarse) | (gc == 0) | (wgc == 0)
     assert inside.mean() > 0.999
-    assert np.abs(gc - wgc)[(gc != 0) & (wgc != 0)].max() <= BWD_ATOL_F32 * max(h, w)
+    assert np.abs(gc - wgc)[(gc != 0) & (wgc != 0)].max() <= BWD_ATOL_F32 * max(h, w) * coarse
 
 
 def test_gradcheck_fp64():
