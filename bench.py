@@ -69,12 +69,173 @@ def cpu_baseline(threads: int) -> dict:
     }
 
 
+POINT_SAMPLE_WORKLOADS = {
+    # mask loss at Cityscapes 1/4 resolution: 200 mask logit maps, 112 x 112 points each
+    "point_sample_masks_256x512_p12544": dict(n=200, c=1, h=256, w=512, p=112 * 112),
+    # feature sampling: 16 maps of 256 channels
+    "point_sample_feat_c256_128x256_p4096": dict(n=16, c=256, h=128, w=256, p=4096),
+}
+
+
+def point_sample_cpu_baseline(x, pts, go) -> dict:
+    """The scalar C oracle of the sampling op on one host core, on a bounded sample (the first
+    maps of the workload, forward + backward)."""
+    from oracle import cpu as oracle_cpu
+
+    per_map = x.shape[1] * pts.shape[1]
+    ns = max(1, min(x.shape[0], 4_000_000 // max(per_map, 1)))
+    xc, pc, gc = x[:ns].cpu().numpy(), pts[:ns].cpu().numpy(), go[:ns].cpu().numpy()
+    t0 = time.perf_counter()
+    oracle_cpu.point_sample_forward(xc, pc)
+    oracle_cpu.point_sample_backward(gc, xc, pc)
+    dt = time.perf_counter() - t0
+    return {
+        "value": ns * per_map / dt,
+        "unit": "points/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": f"first {ns} maps of the workload, forward + backward, scalar C oracle ({dt * 1e3:.0f} ms)",
+    }
+
+
+def bench_point_sample(args, device, rank: int, world: int, distributed: bool) -> None:
+    """`--op point_sample`: PointRend point sampling (grid_sample with border padding at
+    normalised points), forward + backward per step, maps and points resident in HBM.  The maps
+    are sharded over the ranks with no exchange (the op has no parameters): weak scaling."""
+    import torch.distributed as dist
+
+    from unipercept_amd.vision import pointrend  # noqa: F401  (registers the ops, loads libmsda.so)
+
+    name = args.workload if args.workload in POINT_SAMPLE_WORKLOADS else "point_sample_masks_256x512_p12544"
+    cfg = POINT_SAMPLE_WORKLOADS[name]
+    n, c, h, w, p = cfg["n"], cfg["c"], cfg["h"], cfg["w"], cfg["p"]
+    g = torch.Generator(device=device).manual_seed(1234 + rank)
+    x = torch.randn(n, c, h, w, generator=g, device=device)
+    pts = torch.rand(n, p, 2, generator=g, device=device)
+    go = torch.randn(n, c, p, generator=g, device=device)
+    fwd = torch.ops.unipercept.point_sample_fwd
+    bwd = torch.ops.unipercept.point_sample_bwd
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+
+    def step(i):
+        if i is not None:
+            ev[i][0].record()
+        fwd(x, pts, 0, False)
+        if i is not None:
+            ev[i][1].record()
+        bwd(go, x, pts, 0, False)
+        if i is not None:
+            ev[i][2].record()
+
+    def fence():
+        torch.cuda.synchronize(device)
+        if distributed:
+            dist.barrier(device_ids=[device.index])
+            torch.cuda.synchronize(device)
+
+    for _ in range(args.warmup):
+        step(None)
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if distributed:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank != 0:
+        return
+    fwd_ms = statistics.mean(e[0].elapsed_time(e[1]) for e in ev)
+    bwd_ms = statistics.mean(e[1].elapsed_time(e[2]) for e in ev)
+    e4 = 4
+    fwd_bytes = (n * c * h * w + n * p * 2 + n * c * p) * e4
+    bwd_bytes = (n * c * p + 2 * n * c * h * w + 2 * n * p * 2) * e4
+    points = n * c * p
+    traffic = None
+    try:
+        rec = json.loads((ROOT / "profiles" / "hbm_traffic.json").read_text()).get(name)
+        if rec is not None:
+            traffic = rec["backward"]
+    except (OSError, ValueError, KeyError):
+        traffic = None
+    line = {
+        "metric": "point_sample_fwd_bwd_points_per_sec",
+        "value": points * world * args.steps / elapsed,
+        "unit": "points/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": name, "maps_per_gpu": n, "channels": c, "height": h, "width": w,
+            "points_per_map": p, "mode": "bilinear", "align_corners": False,
+            "sampled_points_per_gpu_step": points, "parallelism": f"dp{world}", "collective": None,
+        },
+        "roofline": {
+            "bound": "hbm",
+            "kernel": "msda_point_sample_backward (grad_coords gather + grad_input band kernel, HIP events in the timed loop)",
+            "achieved": bwd_bytes / (bwd_ms * 1e-3) / 1e9,
+            "peak": HBM_PEAK / 1e9,
+            "unit": "GB/s",
+            "frac": bwd_bytes / (bwd_ms * 1e-3) / HBM_PEAK,
+            "traffic": traffic,
+            "algorithmic_bytes_per_launch": bwd_bytes,
+            "avg_launch_ms": bwd_ms,
+        },
+        "phases": {
+            "fwd_ms": fwd_ms, "bwd_ms": bwd_ms,
+            "fwd_points_per_s": points / (fwd_ms * 1e-3),
+            "fwd_hbm_frac": fwd_bytes / (fwd_ms * 1e-3) / HBM_PEAK,
+            "bwd_hbm_frac": bwd_bytes / (bwd_ms * 1e-3) / HBM_PEAK,
+        },
+    }
+    if args.torch_compare:
+        def t_fwd():
+            return torch.nn.functional.grid_sample(x, 2 * pts.unsqueeze(2) - 1, padding_mode="border", align_corners=False)
+
+        def t_fwd_bwd():
+            xx = x.detach().requires_grad_(True)
+            pp = pts.detach().requires_grad_(True)
+            torch.nn.functional.grid_sample(xx, 2 * pp.unsqueeze(2) - 1, padding_mode="border",
+                                            align_corners=False).backward(go.unsqueeze(3))
+
+        res = {}
+        for label, fn in (("fwd_ms", t_fwd), ("fwd_bwd_ms", t_fwd_bwd)):
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize(device)
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(args.steps):
+                fn()
+            b.record()
+            torch.cuda.synchronize(device)
+            res[label] = a.elapsed_time(b) / args.steps
+        line["torch_rocm_grid_sample"] = res
+    if not args.no_cpu_baseline and world == 1:
+        line["cpu_baseline"] = point_sample_cpu_baseline(x, pts, go)
+    print(json.dumps(line), flush=True)
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--op", default="msda", choices=["msda", "point_sample"],
+                    help="msda: the MSDeformAttn hot path (default, the headline metric); "
+                    "point_sample: PointRend point sampling")
+    ap.add_argument("--torch-compare", action="store_true",
+                    help="point_sample: also time PyTorch-ROCm's own grid_sample on the same GPU")
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", default=harness.HEADLINE, choices=sorted(harness.WORKLOADS))
+    ap.add_argument("--workload", default=None,
+                    choices=sorted(harness.WORKLOADS) + sorted(POINT_SAMPLE_WORKLOADS))
     ap.add_argument("--dist", default="R", choices=["R", "U"], help="sampling-location distribution")
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch override")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -115,6 +276,17 @@ def main() -> None:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group("nccl", device_id=device)
+
+    if args.op == "point_sample":
+        bench_point_sample(args, device, rank, world, distributed)
+        if distributed:
+            dist.barrier(device_ids=[local_rank])
+            dist.destroy_process_group()
+        return
+    if args.workload is None:
+        args.workload = harness.HEADLINE
+    if args.workload not in harness.WORKLOADS:
+        raise SystemExit(f"{args.workload} is a point-sampling workload: add --op point_sample")
 
     from unipercept_amd.deform_attn import _ops  # loads libmsda.so (raises if missing)
 

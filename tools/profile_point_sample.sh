@@ -1,16 +1,16 @@
 #!/bin/bash
 # rocprofv3 evidence for the point-sampling kernels (GPU box): kernel trace + three PMC passes.
-#   usage: tools/profile_point_sample.sh <tag> [bench_point_sample args...]
+#   usage: tools/profile_point_sample.sh <tag> [bench.py --op point_sample args...]
 tag=$1; shift
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 out=gpurun_out/prof_$tag
 mkdir -p "$out"
-timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/kt" -- python tools/bench_point_sample.py --iters 20 "$@" > "$out/bench_under_trace.json" 2> "$out/kt.err" || exit 1
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/kt" -- python bench.py --op point_sample --steps 20 --warmup 5 --no-cpu-baseline "$@" > "$out/bench_under_trace.json" 2> "$out/kt.err" || exit 1
 for pass in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
   name=$(echo "$pass" | cut -d' ' -f1)
-  timeout -s KILL 120 rocprofv3 --pmc $pass --output-format csv -d "$out/pmc_$name" -- python tools/bench_point_sample.py --iters 3 "$@" > /dev/null 2> "$out/pmc_$name.err" || exit 1
+  timeout -s KILL 120 rocprofv3 --pmc $pass --output-format csv -d "$out/pmc_$name" -- python bench.py --op point_sample --steps 3 --warmup 1 --no-cpu-baseline "$@" > /dev/null 2> "$out/pmc_$name.err" || exit 1
 done
-timeout -k 10 200 python tools/bench_point_sample.py "$@" > "$out/bench.json" 2> "$out/bench.err" || exit 1
+timeout -k 10 200 python bench.py --op point_sample --torch-compare "$@" > "$out/bench.json" 2> "$out/bench.err" || exit 1
 python - "$out" <<'PY'
 import csv, glob, json, sys, collections
 out = sys.argv[1]

@@ -29,5 +29,28 @@ for d in sorted(glob.glob("gpurun_out/prof_*")):
         "forward": fwd,
         "backward": bwd,
     }
+# point-sampling profiles (tools/profile_point_sample.sh): one summary.json per directory
+for d in sorted(glob.glob("gpurun_out/prof_*point_sample*")):
+    tag = os.path.basename(d)[len("prof_"):]
+    js = f"{d}/summary.json"
+    if not os.path.exists(js):
+        continue
+    shutil.copy(js, f"profiles/summary_{tag}.json")
+    for f in glob.glob(f"{d}/kt/**/*_kernel_stats.csv", recursive=True):
+        shutil.copy(f, f"profiles/{tag}_kernel_stats.csv")
+    s = json.load(open(js))
+    fwd = bwd = 0.0
+    for k, v in s["kernels"].items():
+        b = v.get("hbm_read_bytes", 0.0) + v.get("hbm_write_bytes", 0.0)
+        if "_bwd_" in k:
+            bwd += b
+        else:
+            fwd += b
+    traffic[s["bench"]["config"]["workload"]] = {
+        "source": f"profiles/summary_{tag}.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate "
+        "passes; KiB -> bytes; FETCH_SIZE doubled)",
+        "forward": fwd,
+        "backward": bwd,
+    }
 json.dump(traffic, open("profiles/hbm_traffic.json", "w"), indent=1)
 print(json.dumps(traffic, indent=1))
