@@ -130,7 +130,8 @@ int msda_value_relayout(const void* src, void* dst, int N, int S, int M, int D, 
 
 /*
  * Scratch the backward needs, in bytes (0 when none).  The binned grad_value path keeps its
- * scatter records (64 bytes per sampled point, worst case) and a tile directory there; the
+ * scatter records (64 bytes per sampled point, worst case), a tile directory and a per-head
+ * copy of grad_out (as large as grad_out) there; the
  * atomic paths need an fp32 accumulation image of grad_value for 16-bit value dtypes.
  * `shapes_host`: as for msda_backward (the size depends on it); pass the same value to both.
  */

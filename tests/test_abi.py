@@ -118,13 +118,16 @@ def test_workspace_bytes():
     assert ws(1, 640, 2, 30, 2, 2, 2, _lib.BF16, _lib.BF16, 0) == 640 * 2 * 30 * 4
     # deterministic mode needs none
     assert ws(1, 640, 2, 32, 2, 2, 2, _lib.BF16, _lib.BF16, _lib.FLAG_DETERMINISTIC) == 0
-    # binned path (Cityscapes shapes, batch 8): directory + 64 B per sampled point
+    # binned path (Cityscapes shapes, batch 8): directory + 64 B per sampled point + grad_out copy
     n, s, m, d, l, p = 8, 43008, 8, 32, 3, 4
     tiles = -(-s // 64)  # 64 positions per destination tile
     qblocks = -(-s // 256)
     dir_bytes = n * m * qblocks * tiles * 8
     rec_bytes = n * m * qblocks * 256 * l * p * 4 * 16
-    assert ws(n, s, m, d, s, l, p, _lib.F32, _lib.F32, 0) == ((dir_bytes + 255) // 256) * 256 + rec_bytes
+    g_copy_bytes = n * m * s * d * 4  # per-head copy of grad_out for the destination-side gather
+    assert ws(n, s, m, d, s, l, p, _lib.F32, _lib.F32, 0) == (
+        ((dir_bytes + 255) // 256) * 256 + rec_bytes + g_copy_bytes
+    )
     # atomic scatter on request: nothing for fp32, the fp32 image for bf16
     assert ws(n, s, m, d, s, l, p, _lib.F32, _lib.F32, _lib.FLAG_ATOMIC_SCATTER) == 0
     assert ws(n, s, m, d, s, l, p, _lib.BF16, _lib.F32, _lib.FLAG_ATOMIC_SCATTER) == n * s * m * d * 4

@@ -39,6 +39,13 @@ namespace msda {
 #endif
 constexpr int kAblate = MSDA_ABLATE;
 
+// The query kernel leaves a per-head copy (N, M, Lq, D) of grad_out in the workspace and the
+// tile kernel gathers its rows from that copy: in the (N, Lq, M, D) tensor a head's rows are
+// M*D*e bytes apart and fall on 2 of the 16 channels of the XCD's L2.
+#ifndef MSDA_G_COPY
+#define MSDA_G_COPY 1
+#endif
+
 constexpr int kNotTuned = INT32_MIN;
 constexpr int MSDA_TUNED_ELAYOUT = -8;  // = MSDA_ELAYOUT of the public header
 constexpr int kMaxLevelsTuned = 16;
@@ -515,8 +522,8 @@ __global__ __launch_bounds__(256) void bwd_query_kernel(
     const int64_t* __restrict__ shapes, const int64_t* __restrict__ lsi,
     const LT* __restrict__ loc, const LT* __restrict__ attn, LT* __restrict__ grad_loc,
     LT* __restrict__ grad_attn, float* __restrict__ gv_acc, uint4* __restrict__ records,
-    uint2* __restrict__ dir, int S, int M, int Lq, int L, int P, int LPB, int head_major,
-    PointRows rs, BinPlan plan) {
+    uint2* __restrict__ dir, VT* __restrict__ g_copy, int S, int M, int Lq, int L, int P, int LPB,
+    int head_major, PointRows rs, BinPlan plan) {
   constexpr int CPL = Chunk<VT>::kCPL;
   constexpr int D = G * CPL;
   constexpr int GQ = query_lanes(G);  // lanes per query
@@ -616,6 +623,14 @@ __global__ __launch_bounds__(256) void bwd_query_kernel(
     for (int j = 0; j < NC; ++j)
       Chunk<VT>::load(reinterpret_cast<const char*>(grad_out) + triple * D * sizeof(VT) +
                           (lane + j * GQ) * 16, go[j]);
+    if (g_copy != nullptr && ib == 0 && live) {
+      // the row again, where the tile kernel will look for it: (batch, head, query) order
+      const int64_t hm_row = (static_cast<int64_t>(b) * M + m) * Lq + qb0 + c0 + gg;
+#pragma unroll
+      for (int j = 0; j < NC; ++j)
+        Chunk<VT>::store(reinterpret_cast<char*>(g_copy) + hm_row * D * sizeof(VT) +
+                             (lane + j * GQ) * 16, go[j]);
+    }
 
     // GQ points per pass: after the pass lane j of the group keeps the results of point i0 + j,
     // so the group writes GQ consecutive grad_attn / grad_loc elements with one store each
@@ -720,7 +735,7 @@ __global__ __launch_bounds__(256) void bwd_tile_gather_kernel(
     const VT* __restrict__ grad_out, const int64_t* __restrict__ shapes,
     const int64_t* __restrict__ lsi, const uint4* __restrict__ records,
     const uint2* __restrict__ dir, VT* __restrict__ grad_value, int S, int M, int Lq, int L,
-    BinPlan plan) {
+    BinPlan plan, int g_head_major) {
   constexpr int CPL = Chunk<VT>::kCPL;
   constexpr int D = G * CPL;
   constexpr int PL = 4;                     // lanes per destination position
@@ -773,11 +788,12 @@ __global__ __launch_bounds__(256) void bwd_tile_gather_kernel(
   __syncthreads();
 
   const uint4* slab_records = records + slab * plan.n_qblocks * static_cast<int64_t>(plan.region);
+  // grad_out rows of this head: (N, Lq, M, D) as given, or the per-head copy (N, M, Lq, D)
   const char* go_slab = reinterpret_cast<const char*>(grad_out) +
-                        (static_cast<int64_t>(b) * Lq * M + m) * ROWB;  // + q * M * ROWB
+                        (g_head_major ? slab * Lq : static_cast<int64_t>(b) * Lq * M + m) * ROWB;
   const uint32_t tile_u = static_cast<uint32_t>(tile);
   const int pg = threadIdx.x / PL, pl = threadIdx.x % PL;
-  const int64_t q_stride = static_cast<int64_t>(M) * ROWB;
+  const int64_t q_stride = static_cast<int64_t>(g_head_major ? 1 : M) * ROWB;
 
   float sum[NCH][CPL];
 #pragma unroll
@@ -1083,6 +1099,12 @@ inline int tuned_forward(const void* value, const int64_t* shapes, const int64_t
 #undef MSDA_ARGS
 }
 
+// bytes of the per-head grad_out copy at the end of the binned backward's workspace
+inline size_t g_copy_bytes(int N, int M, int D, int Lq, int dtype_val) {
+  if (!MSDA_G_COPY) return 0;
+  return static_cast<size_t>(N) * M * Lq * D * (dtype_val == 0 ? 4 : 2);
+}
+
 inline int64_t tuned_backward_workspace_bytes(int N, int S, int M, int D, int Lq, int L, int P,
                                               int dtype_val, int dtype_loc, bool allow_binned,
                                               const int64_t* levels_host) {
@@ -1091,7 +1113,7 @@ inline int64_t tuned_backward_workspace_bytes(int N, int S, int M, int D, int Lq
   BinPlan plan;
   size_t dir_b, rec_b;
   if (allow_binned && make_bin_plan(N, S, M, D, Lq, L, P, levels_host, &plan, &dir_b, &rec_b))
-    return static_cast<int64_t>(dir_b + rec_b);
+    return static_cast<int64_t>(dir_b + rec_b + g_copy_bytes(N, M, D, Lq, dtype_val));
   if (dtype_val == 0) return 0;
   return static_cast<int64_t>(N) * S * M * D * 4;  // fp32 accumulation image of grad_value
 }
@@ -1121,6 +1143,8 @@ int tuned_backward_typed(const void* grad_out, const void* value, const int64_t*
   if (binned) {
     uint2* dir = static_cast<uint2*>(workspace);
     uint4* records = reinterpret_cast<uint4*>(static_cast<char*>(workspace) + dir_b);
+    VT* g_copy = MSDA_G_COPY ? reinterpret_cast<VT*>(static_cast<char*>(workspace) + dir_b + rec_b)
+                             : static_cast<VT*>(nullptr);
     const dim3 qgrid(static_cast<unsigned>(plan.n_qblocks) * M, N);
     const size_t qlds = static_cast<size_t>(GPB) * group_stride_slots(LPB, slots) * 16 +
                         static_cast<size_t>(plan.n_tiles) * 8;
@@ -1134,11 +1158,12 @@ int tuned_backward_typed(const void* grad_out, const void* value, const int64_t*
                      static_cast<const VT*>(grad_out), static_cast<const VT*>(value), shapes,    \
                      lsi, static_cast<const LT*>(loc), static_cast<const LT*>(attn),             \
                      static_cast<LT*>(grad_loc), static_cast<LT*>(grad_attn),                    \
-                     static_cast<float*>(nullptr), records, dir, S, M, Lq, L, P, LPB,            \
+                     static_cast<float*>(nullptr), records, dir, g_copy, S, M, Lq, L, P, LPB,    \
                      head_major ? 1 : 0, rs, plan);                                              \
   hipLaunchKernelGGL((bwd_tile_gather_kernel<VT, GG, RPT>), tgrid, dim3(256), tlds, stream,      \
-                     static_cast<const VT*>(grad_out), shapes, lsi, records, dir,                \
-                     static_cast<VT*>(grad_value), S, M, Lq, L, plan)
+                     g_copy ? static_cast<const VT*>(g_copy) : static_cast<const VT*>(grad_out), \
+                     shapes, lsi, records, dir, static_cast<VT*>(grad_value), S, M, Lq, L, plan, \
+                     g_copy ? 1 : 0)
     switch (G) {
       case 4: MSDA_TB(4); break;
       case 8: MSDA_TB(8); break;
@@ -1170,8 +1195,8 @@ int tuned_backward_typed(const void* grad_out, const void* value, const int64_t*
                      static_cast<const VT*>(grad_out), static_cast<const VT*>(value), shapes,    \
                      lsi, static_cast<const LT*>(loc), static_cast<const LT*>(attn),             \
                      static_cast<LT*>(grad_loc), static_cast<LT*>(grad_attn), acc,               \
-                     static_cast<uint4*>(nullptr), static_cast<uint2*>(nullptr), S, M, Lq, L, P, \
-                     LPB, 0, rs, plan)
+                     static_cast<uint4*>(nullptr), static_cast<uint2*>(nullptr),                 \
+                     static_cast<VT*>(nullptr), S, M, Lq, L, P, LPB, 0, rs, plan)
   switch (G) {
     case 4: MSDA_TB(4); break;
     case 8: MSDA_TB(8); break;
