@@ -121,9 +121,10 @@ def test_workspace_bytes():
     # binned path (Cityscapes shapes, batch 8): directory + 64 B per sampled point + grad_out copy
     n, s, m, d, l, p = 8, 43008, 8, 32, 3, 4
     tiles = -(-s // 64)  # 64 positions per destination tile
-    qblocks = -(-s // 256)
+    qb = 192  # queries per query-side workgroup
+    qblocks = -(-s // qb)
     dir_bytes = n * m * qblocks * tiles * 8
-    rec_bytes = n * m * qblocks * 256 * l * p * 4 * 16
+    rec_bytes = n * m * qblocks * qb * l * p * 4 * 16
     g_copy_bytes = n * m * s * d * 4  # per-head copy of grad_out for the destination-side gather
     assert ws(n, s, m, d, s, l, p, _lib.F32, _lib.F32, 0) == (
         ((dir_bytes + 255) // 256) * 256 + rec_bytes + g_copy_bytes
@@ -141,7 +142,7 @@ def test_workspace_bytes():
     s2 = 20 * 24 + 10 * 12 + 5 * 6
     ragged = (ctypes.c_int64 * 6)(20, 24, 10, 12, 5, 6)
     base = ws(1, s2, m, d, s2, l, p, _lib.F32, _lib.F32, 0)
-    qb2 = -(-s2 // 256)
+    qb2 = -(-s2 // 192)
     r256 = lambda x: -(-x // 256) * 256
     assert (ws_h(1, s2, m, d, s2, l, p, _lib.F32, _lib.F32, 0, ragged) - base
             == r256(m * qb2 * 14 * 8) - r256(m * qb2 * 10 * 8))
