@@ -6,10 +6,23 @@ generators) in ``sources/unipercept/vision/pointrend.py`` by these imports.
 """
 
 from unipercept_amd.vision.pointrend import (  # noqa: F401
+    BinsMode,
+    bins_by_values,
     logit_uncertainty,
+    map_in_bins,
     random_points,
+    random_points_with_bins,
     random_points_with_importance,
     sample,
 )
 
-__all__ = ["logit_uncertainty", "random_points", "random_points_with_importance", "sample"]
+__all__ = [
+    "BinsMode",
+    "bins_by_values",
+    "logit_uncertainty",
+    "map_in_bins",
+    "random_points",
+    "random_points_with_bins",
+    "random_points_with_importance",
+    "sample",
+]

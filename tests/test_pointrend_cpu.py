@@ -133,3 +133,64 @@ def test_importance_sampling_host_logic(monkeypatch):
     # a quarter of the points is drawn afresh when the ratio says so
     points = pointrend.random_points_with_importance(src, 8, 2, importance_sample_ratio=0.75)
     assert points.shape == (1, 8, 2)
+
+
+# ---- value-bin helpers: tests/unipercept/vision/test_pointrend.py:77-207 of the reference ----
+def _masked_mean(t, m):
+    return torch.nanmean(t.masked_fill(~m, torch.nan), dim=1, keepdim=True)
+
+
+def _count(t, m):
+    return m.int().sum(dim=1, keepdim=True)
+
+
+@pytest.mark.parametrize("use_batch", [False, True])
+@pytest.mark.parametrize("mode", ["linear", "quantile"])
+def test_bins_by_values(use_batch, mode):
+    values = torch.rand(4, 30)
+    bins = pointrend.bins_by_values(values, 10, use_batch=use_batch, mode=mode)
+    assert bins.shape == (4, 10) and bins.min() >= 0 and bins.max() <= 1 + 1e-5
+    assert torch.all(bins[:, 1:] >= bins[:, :-1])
+    if not use_batch:  # one set of boundaries for the whole batch
+        assert torch.equal(bins[0], bins[1])
+    # the last boundary lies just above the largest value that counts
+    top = values.max(dim=1).values if use_batch else values.max().expand(4)
+    assert torch.all(bins[:, -1] > top) and torch.all(bins[:, -1] - top <= 1e-5)
+
+
+@pytest.mark.parametrize("use_batch", [False, True])
+@pytest.mark.parametrize("mode", ["linear", "quantile"])
+def test_map_in_bins(use_batch, mode):
+    values = torch.rand(2, 1000)
+    mask = values > 0.1
+    bins = pointrend.bins_by_values(values, 10, mask=mask, use_batch=use_batch, mode=mode)
+    assert pointrend.map_in_bins(values, bins, _masked_mean).shape == (2, 10)
+    sources = torch.rand(2, 1000)
+    logv = sources.log1p()
+    bins = pointrend.bins_by_values(logv, 10, use_batch=use_batch, mode=mode)
+    assert pointrend.map_in_bins(sources, bins, _masked_mean, values=logv).shape == (2, 10)
+    counts = pointrend.map_in_bins(sources, bins, _count, values=logv)
+    assert counts.shape == (2, 10) and counts.sum(dim=1).tolist() == [1000, 1000]
+    if mode == "quantile" and use_batch:
+        assert counts.min() >= 99 and counts.max() <= 101  # equally populated
+    mask = sources > 0.1
+    bins = pointrend.bins_by_values(logv, 10, mask=mask, use_batch=use_batch, mode=mode)
+    counts = pointrend.map_in_bins(sources, bins, _count, values=logv, mask=mask)
+    assert counts.shape == (2, 10) and counts.sum(dim=1).tolist() == mask.sum(dim=1).tolist()
+
+
+@pytest.mark.parametrize("use_batch", [False, True])
+@pytest.mark.parametrize("mode", ["linear", "quantile"])
+def test_random_points_with_bins(use_batch, mode):
+    sources = torch.rand(2, 1, 16, 16)
+    points = pointrend.random_points_with_bins(
+        sources, 8, use_batch=use_batch, mode=mode, n_bins=10, values=sources.log1p()
+    )
+    assert points.shape == (2, 8, 2) and points.min() >= 0 and points.max() <= 1
+
+
+def test_bins_mode_strings():
+    assert pointrend.BinsMode("linear") is pointrend.BinsMode.LINEAR
+    assert f"{pointrend.BinsMode.QUANTILE}" == "quantile"
+    with pytest.raises(ValueError):
+        pointrend.bins_by_values(torch.rand(1, 5), 2, mode="cubic")

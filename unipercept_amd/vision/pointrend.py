@@ -5,13 +5,17 @@
 ``msda_point_sample_forward/_backward`` (``include/msda.h``).  ``random_points``,
 ``logit_uncertainty`` and ``random_points_with_importance`` (same file, :79-300) are the callers
 either side of it and stay plain PyTorch; they are here so that a model's point-based mask loss
-runs unchanged with the sampling step on the HIP path.
+runs unchanged with the sampling step on the HIP path.  The value-bin helpers of the same module
+(``bins_by_values``, ``map_in_bins``, ``random_points_with_bins``, :303-542) are host-side
+PyTorch logic around ``random_points``; they are restated so that the module is whole.
 
 There is no CPU implementation of ``sample``: tensors that are not on a ROCm device raise.
 """
 
 from __future__ import annotations
 
+import enum
+import math
 from collections.abc import Callable
 
 import torch
@@ -220,3 +224,93 @@ def random_points_with_importance(
     if n_random > 0:
         chosen = torch.cat((chosen, random_points(source, n_random, d_coord, mask)), dim=1)
     return chosen
+
+
+class BinsMode(str, enum.Enum):
+    """How ``bins_by_values`` places its boundaries (reference:
+    sources/unipercept/vision/pointrend.py:303-309)."""
+
+    QUANTILE = "quantile"
+    LINEAR = "linear"
+
+    def __str__(self) -> str:  # behaves like the reference's StrEnum in format strings
+        return self.value
+
+
+@torch.no_grad()
+def bins_by_values(source: torch.Tensor, n_bins: int, mask: torch.Tensor | None = None,
+                   use_batch: bool = False, mode: BinsMode | str = BinsMode.QUANTILE,
+                   eps: float = 1e-6) -> torch.Tensor:
+    """Upper boundaries (B, n_bins) of ``n_bins`` value bins of ``source`` (B, C, ...): equally
+    populated ("quantile") or equally wide ("linear"), over the whole batch or per sample
+    (reference: sources/unipercept/vision/pointrend.py:312-391).  ``mask`` selects the values
+    that count; without it NaNs are left out."""
+    if source.dim() < 2:
+        raise ValueError(f"source must be (B, C, ...), got {tuple(source.shape)}")
+    n_batch = source.shape[0]
+    if use_batch:
+        flat = source.flatten(1)
+        flat_mask = None if mask is None else mask.flatten(1)  # same cut as the values
+        rows = [
+            bins_by_values(flat[i][None], n_bins, None if flat_mask is None else flat_mask[i][None],
+                           False, mode, eps)
+            for i in range(n_batch)
+        ]
+        return torch.cat(rows, dim=0)
+    values = source[mask] if mask is not None else source[~source.isnan()]
+    mode = BinsMode(mode)
+    if mode is BinsMode.QUANTILE:
+        q = torch.linspace(0, 1, n_bins + 1, device=values.device)[1:]
+        edges = torch.quantile(values, q) + eps
+    else:
+        edges = torch.linspace(float(values.min()), float(values.max()) + eps, n_bins + 1,
+                               device=values.device)[1:]
+    return edges[None].repeat(n_batch, 1)
+
+
+def map_in_bins(source: torch.Tensor, bins: torch.Tensor,
+                fn: Callable[[torch.Tensor, torch.Tensor], torch.Tensor],
+                mask: torch.Tensor | None = None, values: torch.Tensor | None = None,
+                **kwargs) -> torch.Tensor:
+    """Calls ``fn(source, in_bin_mask)`` for every non-empty bin of ``values`` (default:
+    ``source``) and concatenates the results along dim 1 (reference:
+    sources/unipercept/vision/pointrend.py:394-462)."""
+    if source.dim() < 2 or bins.dim() not in (1, 2):
+        raise ValueError("expected source (B, C, ...) and bins (B, N) (or (N,) for one sample)")
+    if values is None:
+        values = source
+    which = torch.searchsorted(bins, values, right=True)
+    outputs = []
+    for i in range(bins.shape[-1]):
+        in_bin = which == i
+        if mask is not None:
+            in_bin = in_bin & mask
+        if in_bin.any():
+            outputs.append(fn(source, in_bin))
+    return torch.cat(outputs, dim=1)
+
+
+def random_points_with_bins(source: torch.Tensor, n_points: int, d_coord: int = 2,
+                            mask: torch.Tensor | None = None, n_bins: int = 10,
+                            use_batch: bool = False, mode: BinsMode | str = BinsMode.QUANTILE,
+                            values: torch.Tensor | None = None) -> torch.Tensor:
+    """Points (N, n_points, d_coord) drawn evenly over the value bins of every sample: the
+    values are binned, every non-empty bin contributes the same number of points inside its own
+    pixels, and the list is cut to ``n_points`` (reference:
+    sources/unipercept/vision/pointrend.py:465-542)."""
+    if values is None:
+        values = source
+    if mask is None:
+        mask = torch.ones_like(values, dtype=torch.bool)
+    bins = bins_by_values(source, n_bins, mask=mask, mode=mode, use_batch=use_batch)
+    points = []
+    for s, m, b, v in zip(source, mask, bins, values, strict=True):
+        # s, m, v: one sample (C, ...); b: its (n_bins,) boundaries
+        non_empty = int(map_in_bins(s, b, lambda _, in_bin: in_bin.any()[None, None], mask=m, values=v).sum())
+        per_bin = math.ceil(n_points / max(non_empty, 1))
+        chosen = map_in_bins(
+            s, b, lambda src, in_bin: random_points(src[None], per_bin, d_coord, mask=in_bin[None]),
+            mask=m, values=v,
+        )
+        points.append(chosen[0, :n_points])
+    return torch.stack(points, dim=0)
