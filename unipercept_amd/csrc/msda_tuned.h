@@ -377,6 +377,17 @@ __device__ __forceinline__ void stage_chunk(const LevelInfo* lv, const LT* __res
 // ---------------------------------------------------------------------------------------------
 // Forward
 // ---------------------------------------------------------------------------------------------
+// Rows of 64 bytes (G = 4 chunks: fp32 D = 16, 16-bit D = 32): the two x-neighbouring corners of
+// a footprint are then 128 contiguous bytes of the per-head copy.  Eight lanes share a query, the
+// upper four take the x0 + 1 column: one load instruction fetches both corners of a footprint
+// row as one 128-byte piece instead of two 64-byte halves of (mostly) the same line from two
+// instructions, and the two columns are summed apart until the end.
+#ifndef MSDA_FWD_PAIR
+#define MSDA_FWD_PAIR 1
+#endif
+__host__ __device__ constexpr bool fwd_pairs(int G) { return MSDA_FWD_PAIR && G == 4; }
+__host__ __device__ constexpr int fwd_query_lanes(int G) { return fwd_pairs(G) ? 2 * G : G; }
+
 template <typename VT, typename LT, int G>
 __global__ __launch_bounds__(256) void fwd_tuned_kernel(
     const VT* __restrict__ value, const int64_t* __restrict__ shapes,
@@ -386,9 +397,11 @@ __global__ __launch_bounds__(256) void fwd_tuned_kernel(
   constexpr int CPL = Chunk<VT>::kCPL;
   constexpr int D = G * CPL;
   // one chunk per lane here: two (as in the backward query kernel) measured 20 % slower, the
-  // forward has nothing but the gather to amortise and wants the extra loads in flight
-  constexpr int GQ = G;          // lanes per query
-  constexpr int NC = G / GQ;     // 16-byte chunks of a row per lane: lane, lane + GQ, ...
+  // forward has nothing but the gather to amortise and wants the extra loads in flight.
+  // 64-byte rows (G = 4) are taken by 8 lanes per query, see fwd_pairs().
+  constexpr bool PAIR = fwd_pairs(G);
+  constexpr int GQ = fwd_query_lanes(G);  // lanes per query
+  constexpr int NC = 1;          // 16-byte chunks of a row per lane
   constexpr int GPB = 256 / GQ;  // queries per block
   extern __shared__ uint4 lds[];
   __shared__ LevelInfo lv[kMaxLevelsTuned];
@@ -404,7 +417,8 @@ __global__ __launch_bounds__(256) void fwd_tuned_kernel(
   // value is (N,S,M,D), or (N,M,S,D) when head_major: bytes between positions / to head m
   const uint32_t rowb = static_cast<uint32_t>(head_major ? 1 : M) * D * sizeof(VT);
   const uint32_t headb = static_cast<uint32_t>(m) * (head_major ? S : 1) * D * sizeof(VT);
-  const int g = threadIdx.x / GQ, lane = threadIdx.x % GQ;
+  const int g = threadIdx.x / GQ, lane = threadIdx.x % G;
+  const bool right = PAIR && (threadIdx.x % GQ) >= G;  // this lane takes the x0 + 1 corners
   const bool live = g < nq;
   const char* vb = reinterpret_cast<const char*>(value) +
                    static_cast<int64_t>(b) * S * M * D * static_cast<int64_t>(sizeof(VT));
@@ -431,25 +445,42 @@ __global__ __launch_bounds__(256) void fwd_tuned_kernel(
         const float w[4] = {__uint_as_float(wr.x), __uint_as_float(wr.y), __uint_as_float(wr.z),
                             __uint_as_float(wr.w)};
         const uint32_t o[4] = {orr.x & ~15u, orr.y & ~15u, orr.z & ~15u, orr.w & ~15u};
-        float v[4][NC][CPL];
+        if constexpr (PAIR) {
+          // the lane's column of the footprint: rows y0 and y0 + 1
+          const uint32_t oa = right ? o[1] : o[0], ob = right ? o[3] : o[2];
+          const float wa = right ? w[1] : w[0], wb = right ? w[3] : w[2];
+          float va[CPL], vbot[CPL];
+          Chunk<VT>::load(vb + (oa + lane_b), va);
+          Chunk<VT>::load(vb + (ob + lane_b), vbot);
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
+          for (int c = 0; c < CPL; ++c) acc[0][c] = fmaf(wb, vbot[c], fmaf(wa, va[c], acc[0][c]));
+        } else {
+          float v[4][NC][CPL];
 #pragma unroll
-          for (int j = 0; j < NC; ++j) Chunk<VT>::load(vb + (o[k] + lane_b) + j * GQ * 16, v[k][j]);
+          for (int k = 0; k < 4; ++k)
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
+            for (int j = 0; j < NC; ++j) Chunk<VT>::load(vb + (o[k] + lane_b) + j * GQ * 16, v[k][j]);
 #pragma unroll
-          for (int j = 0; j < NC; ++j)
+          for (int k = 0; k < 4; ++k)
 #pragma unroll
-            for (int c = 0; c < CPL; ++c) acc[j][c] = fmaf(w[k], v[k][j][c], acc[j][c]);
+            for (int j = 0; j < NC; ++j)
+#pragma unroll
+              for (int c = 0; c < CPL; ++c) acc[j][c] = fmaf(w[k], v[k][j][c], acc[j][c]);
+        }
       }
     }
   }
   if (!live) return;
+  if constexpr (PAIR) {
+    // left and right columns were summed apart: lane and lane + G hold the two halves of a sum
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) acc[0][c] += __shfl_xor(acc[0][c], G);
+    if (right) return;
+  }
   const int64_t triple = (static_cast<int64_t>(b) * Lq + q0 + g) * M + m;
 #pragma unroll
   for (int j = 0; j < NC; ++j)
-    Chunk<VT>::store(reinterpret_cast<char*>(out) + triple * D * sizeof(VT) + (lane + j * GQ) * 16,
+    Chunk<VT>::store(reinterpret_cast<char*>(out) + triple * D * sizeof(VT) + (lane + j * G) * 16,
                      acc[j]);
 }
 
@@ -941,7 +972,7 @@ inline bool tuned_shape_ok(int N, int S, int M, int D, int Lq, int L, int P, int
   const int esize = cpl == 4 ? 4 : 2;
   if (static_cast<int64_t>(S) * M * D * esize > static_cast<int64_t>(UINT32_MAX)) return false;
   if (N > 65535) return false;
-  const int GPB = 256 / G;
+  const int GPB = 256 / (2 * G);  // fewest queries per workgroup of any kernel
   if ((static_cast<int64_t>(Lq) + GPB - 1) / GPB * M > INT32_MAX) return false;
   *G_out = G;
   return true;
@@ -1063,7 +1094,7 @@ int tuned_forward_typed(const void* value, const int64_t* shapes, const int64_t*
                         int L, int P, int G, bool head_major, bool packed, hipStream_t stream) {
   const PointRows rs = packed ? PointRows{3 * L * P, 3 * L * P} : PointRows{2 * L * P, L * P};
   if (packed) attn = static_cast<const LT*>(loc) + 2 * L * P;  // the weights follow the pairs
-  const int GQ = G;
+  const int GQ = fwd_query_lanes(G);
   const int GPB = 256 / GQ;
   const dim3 grid(static_cast<unsigned>((Lq + GPB - 1) / GPB) * M, N);
   const int LPB = stage_points_per_pass(GQ, L * P, stage_slots(kStageFwd));
