@@ -385,10 +385,11 @@ __device__ __forceinline__ void stage_chunk(const LevelInfo* lv, const LT* __res
 #ifndef MSDA_FWD_PAIR
 #define MSDA_FWD_PAIR 1
 #endif
-__host__ __device__ constexpr bool fwd_pairs(int G) { return MSDA_FWD_PAIR && G == 4; }
-__host__ __device__ constexpr int fwd_query_lanes(int G) { return fwd_pairs(G) ? 2 * G : G; }
+// Measured on bf16 D = 32: 0.62 -> 0.58 ms for 12 points per query, 0.85 -> 0.78 ms for 16, but
+// 1.49 -> 1.56 ms for 32 points (4 levels x 8 points), so the pairs are used up to 16 points.
+inline bool fwd_pairs(int G, int LP) { return MSDA_FWD_PAIR && G == 4 && LP <= 16; }
 
-template <typename VT, typename LT, int G>
+template <typename VT, typename LT, int G, bool PAIR = false>
 __global__ __launch_bounds__(256) void fwd_tuned_kernel(
     const VT* __restrict__ value, const int64_t* __restrict__ shapes,
     const int64_t* __restrict__ lsi, const LT* __restrict__ loc, const LT* __restrict__ attn,
@@ -398,9 +399,9 @@ __global__ __launch_bounds__(256) void fwd_tuned_kernel(
   constexpr int D = G * CPL;
   // one chunk per lane here: two (as in the backward query kernel) measured 20 % slower, the
   // forward has nothing but the gather to amortise and wants the extra loads in flight.
-  // 64-byte rows (G = 4) are taken by 8 lanes per query, see fwd_pairs().
-  constexpr bool PAIR = fwd_pairs(G);
-  constexpr int GQ = fwd_query_lanes(G);  // lanes per query
+  // 64-byte rows (G = 4) may be taken by 8 lanes per query (PAIR), see fwd_pairs().
+  static_assert(!PAIR || G == 4, "pairs are for 64-byte rows");
+  constexpr int GQ = PAIR ? 2 * G : G;  // lanes per query
   constexpr int NC = 1;          // 16-byte chunks of a row per lane
   constexpr int GPB = 256 / GQ;  // queries per block
   extern __shared__ uint4 lds[];
@@ -1094,20 +1095,27 @@ int tuned_forward_typed(const void* value, const int64_t* shapes, const int64_t*
                         int L, int P, int G, bool head_major, bool packed, hipStream_t stream) {
   const PointRows rs = packed ? PointRows{3 * L * P, 3 * L * P} : PointRows{2 * L * P, L * P};
   if (packed) attn = static_cast<const LT*>(loc) + 2 * L * P;  // the weights follow the pairs
-  const int GQ = fwd_query_lanes(G);
+  const bool pair = fwd_pairs(G, L * P);
+  const int GQ = pair ? 2 * G : G;
   const int GPB = 256 / GQ;
   const dim3 grid(static_cast<unsigned>((Lq + GPB - 1) / GPB) * M, N);
   const int LPB = stage_points_per_pass(GQ, L * P, stage_slots(kStageFwd));
   const size_t lds = static_cast<size_t>(GPB) * group_stride_slots(LPB, 2) * 16;
-#define MSDA_TF(GG)                                                                             \
-  hipLaunchKernelGGL((fwd_tuned_kernel<VT, LT, GG>), grid, dim3(256), lds, stream,              \
+#define MSDA_TF(GG, PP)                                                                         \
+  hipLaunchKernelGGL((fwd_tuned_kernel<VT, LT, GG, PP>), grid, dim3(256), lds, stream,          \
                      static_cast<const VT*>(value), shapes, lsi, static_cast<const LT*>(loc),   \
                      static_cast<const LT*>(attn), static_cast<VT*>(out), S, M, Lq, L, P, LPB,   \
                      head_major ? 1 : 0, rs)
   switch (G) {
-    case 4: MSDA_TF(4); break;
-    case 8: MSDA_TF(8); break;
-    default: MSDA_TF(16); break;
+    case 4:
+      if (pair) {
+        MSDA_TF(4, true);
+      } else {
+        MSDA_TF(4, false);
+      }
+      break;
+    case 8: MSDA_TF(8, false); break;
+    default: MSDA_TF(16, false); break;
   }
 #undef MSDA_TF
   const hipError_t e = hipGetLastError();
