@@ -221,7 +221,27 @@ def bench_point_sample(args, device, rank: int, world: int, distributed: bool) -
         line["torch_rocm_grid_sample"] = res
     if not args.no_cpu_baseline and world == 1:
         line["cpu_baseline"] = point_sample_cpu_baseline(x, pts, go)
-    print(json.dumps(line), flush=True)
+    emit_result(line)
+
+
+_RESULT_OUT = None
+
+
+def _claim_stdout() -> None:
+    """Keeps the process's real stdout for the ONE JSON line and sends everything else that
+    writes to file descriptor 1 (RCCL prints a version banner there when a communicator is
+    created) to stderr."""
+    global _RESULT_OUT
+    if _RESULT_OUT is None:
+        sys.stdout.flush()
+        _RESULT_OUT = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
+
+
+def emit_result(line: dict) -> None:
+    out = _RESULT_OUT or sys.stdout
+    out.write(json.dumps(line) + "\n")
+    out.flush()
 
 
 def main() -> None:
@@ -250,6 +270,7 @@ def main() -> None:
     ap.add_argument("--no-head-major", action="store_true",
                     help="gather from the (N,S,M,D) value as given instead of a per-head copy")
     args = ap.parse_args()
+    _claim_stdout()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -491,7 +512,7 @@ def main() -> None:
         if not args.no_cpu_baseline and world == 1:
             threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
             line["cpu_baseline"] = cpu_baseline(threads)
-        print(json.dumps(line), flush=True)
+        emit_result(line)
 
     if distributed:
         dist.barrier(device_ids=[local_rank])
