@@ -22,7 +22,10 @@ import sys
 import time
 from pathlib import Path
 
-import torch
+# RCCL over xGMI between the ranks of one node needs dmabuf IPC on this driver stack
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch  # noqa: E402
 
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
