@@ -762,7 +762,7 @@ __global__ __launch_bounds__(256) void bwd_query_kernel(
 // the queries that hit one patch are neighbours) and accumulate in registers.  No LDS row stage,
 // no float atomics, four barriers per round; the tile is stored from registers at the end.
 // ---------------------------------------------------------------------------------------------
-template <typename VT, int G, int RPT>
+template <typename VT, int G, int RPT, int U>
 __global__ __launch_bounds__(256) void bwd_tile_gather_kernel(
     const VT* __restrict__ grad_out, const int64_t* __restrict__ shapes,
     const int64_t* __restrict__ lsi, const uint4* __restrict__ records,
@@ -775,7 +775,6 @@ __global__ __launch_bounds__(256) void bwd_tile_gather_kernel(
   constexpr int NCH = D / (PL * CPL);       // 16-byte chunks of a row per lane
   constexpr int R = 256 * RPT;              // records per round
   constexpr int ROWB = D * sizeof(VT);      // bytes of one grad_out row of one head
-  constexpr int U = NCH >= 4 ? 2 : 8 / NCH;  // entries fetched per walk step (8 row loads)
   static_assert(NCH >= 1 && NCH * PL * CPL == D, "head dim must split into 4 lanes of chunks");
   static_assert(TS == 64, "the bucket scan is one wave wide");
   extern __shared__ uint4 lds[];
@@ -1192,9 +1191,21 @@ int tuned_backward_typed(const void* grad_out, const void* value, const int64_t*
                         static_cast<size_t>(plan.n_tiles) * 8;
     const dim3 tgrid(static_cast<unsigned>(plan.n_tiles) * M, N);
     const size_t TSz = static_cast<size_t>(1) << plan.ts_shift;
-    constexpr int RPT = 4;  // records per thread and round of the gather-walk tile kernel
-    const size_t tlds = 4 * 256 * RPT * 8 + (2 * TSz + 1) * 4 +
+    // Two shapes of the tile kernel.  "Light": rounds of 512 records, 3-4 entries (6 / 4 row
+    // loads) per walk step: 64-74 registers and 19 KB of LDS, 6-8 workgroups per CU, whose phases
+    // overlap better (headline shapes: 1.11 -> 1.02 ms).  "Heavy": rounds of 1024 records, 8 row
+    // loads per step, 5 workgroups per CU: fewer rounds for tiles with thousands of records
+    // (4 levels x 8 points: light measured 1 % slower on the whole backward).
+    const double rec_per_tile = 1.3 * static_cast<double>(Lq) * L * P / plan.n_tiles;
+    const bool light = rec_per_tile <= 1536.0;
+    const int RPTv = light ? 2 : 4;
+    const size_t tlds = 4 * 256 * static_cast<size_t>(RPTv) * 8 + (2 * TSz + 1) * 4 +
                         (2 * static_cast<size_t>(plan.n_qblocks) + 1) * 4;
+#define MSDA_TILE(GG, RR, UU)                                                                    \
+  hipLaunchKernelGGL((bwd_tile_gather_kernel<VT, GG, RR, UU>), tgrid, dim3(256), tlds, stream,   \
+                     g_copy ? static_cast<const VT*>(g_copy) : static_cast<const VT*>(grad_out), \
+                     shapes, lsi, records, dir, static_cast<VT*>(grad_value), S, M, Lq, L, plan, \
+                     g_copy ? 1 : 0)
 #define MSDA_TB(GG)                                                                              \
   hipLaunchKernelGGL((bwd_query_kernel<VT, LT, GG, 1>), qgrid, dim3(256), qlds, stream,          \
                      static_cast<const VT*>(grad_out), static_cast<const VT*>(value), shapes,    \
@@ -1202,16 +1213,18 @@ int tuned_backward_typed(const void* grad_out, const void* value, const int64_t*
                      static_cast<LT*>(grad_loc), static_cast<LT*>(grad_attn),                    \
                      static_cast<float*>(nullptr), records, dir, g_copy, S, M, Lq, L, P, LPB,    \
                      head_major ? 1 : 0, rs, plan);                                              \
-  hipLaunchKernelGGL((bwd_tile_gather_kernel<VT, GG, RPT>), tgrid, dim3(256), tlds, stream,      \
-                     g_copy ? static_cast<const VT*>(g_copy) : static_cast<const VT*>(grad_out), \
-                     shapes, lsi, records, dir, static_cast<VT*>(grad_value), S, M, Lq, L, plan, \
-                     g_copy ? 1 : 0)
+  if (light) {                                                                                   \
+    MSDA_TILE(GG, 2, (GG / 4 >= 4 ? 2 : GG / 4 == 2 ? 3 : 4));                                   \
+  } else {                                                                                       \
+    MSDA_TILE(GG, 4, (GG / 4 >= 4 ? 2 : 8 / (GG / 4)));                                          \
+  }
     switch (G) {
       case 4: MSDA_TB(4); break;
       case 8: MSDA_TB(8); break;
       default: MSDA_TB(16); break;
     }
 #undef MSDA_TB
+#undef MSDA_TILE
     e = hipGetLastError();
     return e == hipSuccess ? 0 : static_cast<int>(e);
   }
