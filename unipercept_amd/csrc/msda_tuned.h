@@ -1191,15 +1191,13 @@ int tuned_backward_typed(const void* grad_out, const void* value, const int64_t*
                         static_cast<size_t>(plan.n_tiles) * 8;
     const dim3 tgrid(static_cast<unsigned>(plan.n_tiles) * M, N);
     const size_t TSz = static_cast<size_t>(1) << plan.ts_shift;
-    // Two shapes of the tile kernel.  "Light": rounds of 512 records, 3-4 entries (6 / 4 row
-    // loads) per walk step: 64-74 registers and 19 KB of LDS, 6-8 workgroups per CU, whose phases
-    // overlap better (headline shapes: 1.11 -> 1.02 ms).  "Heavy": rounds of 1024 records, 8 row
-    // loads per step, 5 workgroups per CU: fewer rounds for tiles with thousands of records
-    // (4 levels x 8 points: light measured 1 % slower on the whole backward).
-    const double rec_per_tile = 1.3 * static_cast<double>(Lq) * L * P / plan.n_tiles;
-    const bool light = rec_per_tile <= 1536.0;
-    const int RPTv = light ? 2 : 4;
-    const size_t tlds = 4 * 256 * static_cast<size_t>(RPTv) * 8 + (2 * TSz + 1) * 4 +
+    // Rounds of 512 records (2 per thread) and 3 entries per walk step (2 for rows of 16 chunks):
+    // 64-74 registers and 19 KB of LDS, so 6-8 workgroups per CU whose phases overlap.  Measured
+    // against rounds of 1024 records with 8 row loads per step (94 registers, 5 workgroups per
+    // CU): headline shapes 1.11 -> 1.01 ms, and no slower with 4 levels x 8 points or in bf16;
+    // rounds of 768 or 256 records and 2 / 4 / 6 / 8 entries per step are all slower.
+    constexpr int RPT = 2;
+    const size_t tlds = 4 * 256 * static_cast<size_t>(RPT) * 8 + (2 * TSz + 1) * 4 +
                         (2 * static_cast<size_t>(plan.n_qblocks) + 1) * 4;
 #define MSDA_TILE(GG, RR, UU)                                                                    \
   hipLaunchKernelGGL((bwd_tile_gather_kernel<VT, GG, RR, UU>), tgrid, dim3(256), tlds, stream,   \
@@ -1213,11 +1211,7 @@ int tuned_backward_typed(const void* grad_out, const void* value, const int64_t*
                      static_cast<LT*>(grad_loc), static_cast<LT*>(grad_attn),                    \
                      static_cast<float*>(nullptr), records, dir, g_copy, S, M, Lq, L, P, LPB,    \
                      head_major ? 1 : 0, rs, plan);                                              \
-  if (light) {                                                                                   \
-    MSDA_TILE(GG, 2, (GG / 4 >= 4 ? 2 : GG / 4 == 2 ? 3 : 4));                                   \
-  } else {                                                                                       \
-    MSDA_TILE(GG, 4, (GG / 4 >= 4 ? 2 : 8 / (GG / 4)));                                          \
-  }
+  MSDA_TILE(GG, RPT, (GG >= 16 ? 2 : 3))
     switch (G) {
       case 4: MSDA_TB(4); break;
       case 8: MSDA_TB(8); break;
