@@ -196,7 +196,7 @@ def test_point_sample_argument_errors():
         return lib.msda_point_sample_forward(inp, coords, out, *dims, dtype, mode, 0, None)
 
     def bwd(go=FAKE, inp=FAKE, coords=FAKE, gi=FAKE, gc=FAKE, dims=(1, 1, 2, 2, 3), dtype=0, mode=0):
-        return lib.msda_point_sample_backward(go, inp, coords, gi, gc, *dims, dtype, mode, 0, None)
+        return lib.msda_point_sample_backward(go, inp, coords, gi, gc, None, 0, *dims, dtype, mode, 0, None)
 
     assert fwd(inp=None) == -1 and fwd(out=None) == -1 and bwd(gc=None) == -1
     assert fwd(dims=(0, 1, 2, 2, 3)) == -2 and bwd(dims=(1, 1, 2, 2, 0)) == -2
@@ -205,3 +205,9 @@ def test_point_sample_argument_errors():
     assert bwd(dtype=_lib.BF16) == -3 and bwd(dtype=_lib.F16) == -3  # 16-bit callers convert
     assert fwd(inp=FAKE + 2) == -4 and bwd(gi=FAKE + 2) == -4
     assert fwd(dtype=_lib.F64, coords=FAKE + 4) == -4
+    # optional scratch of the backward: 2 * P point indices + 65 offsets per sample, as int32
+    ws = lib.msda_point_sample_workspace_bytes
+    assert ws(200, 1, 256, 512, 12544, _lib.F32) == (200 * 2 * 12544 + 200 * 65) * 4
+    assert ws(200, 1, 256, 512, 12544, _lib.BF16) == 0  # the backward takes fp32 / fp64
+    assert ws(1, 2, 3, 9000, 700, _lib.F32) == 0  # too wide for LDS bands: atomic path, no lists
+    assert ws(0, 1, 2, 2, 3, _lib.F32) == 0

@@ -37,10 +37,24 @@ def _abi(inp, coords, grad_out, mode, align):
     rc = lib.msda_point_sample_forward(x.data_ptr(), pc.data_ptr(), out.data_ptr(), n, c, h, w, p,
                                        code, mcode, int(align), st)
     assert rc == 0, rc
+    # with the optional point-list workspace, and without it: the same gradients
+    nbytes = lib.msda_point_sample_workspace_bytes(n, c, h, w, p, code)
+    ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device="cuda")
     rc = lib.msda_point_sample_backward(go.data_ptr(), x.data_ptr(), pc.data_ptr(), gi.data_ptr(),
-                                        gc.data_ptr(), n, c, h, w, p, code, mcode, int(align), st)
+                                        gc.data_ptr(), ws.data_ptr(), nbytes, n, c, h, w, p, code,
+                                        mcode, int(align), st)
+    assert rc == 0, rc
+    gi2 = torch.full_like(x, float("nan"))
+    gc2 = torch.full_like(pc, float("nan"))
+    rc = lib.msda_point_sample_backward(go.data_ptr(), x.data_ptr(), pc.data_ptr(), gi2.data_ptr(),
+                                        gc2.data_ptr(), None, 0, n, c, h, w, p, code, mcode,
+                                        int(align), st)
     assert rc == 0, rc
     torch.cuda.synchronize()
+    tol = 1e-12 if x.dtype == torch.float64 else 1e-5
+    assert (gi - gi2).abs().max() <= tol * max(1.0, float(gi2.abs().max()))
+    # (channel slices add their parts of grad_coords with atomics: last-bit differences)
+    assert (gc - gc2).abs().max() <= tol * max(1.0, float(gc2.abs().max()))
     return out.cpu().numpy(), gi.cpu().numpy(), gc.cpu().numpy()
 
 
@@ -225,4 +239,5 @@ def test_abi_rejects_16bit_backward_and_bad_mode():
     args = (x.data_ptr(), pc.data_ptr(), o.data_ptr(), 1, 1, 2, 2, 1)
     assert lib.msda_point_sample_forward(*args, _lib.F32, 7, 0, None) == -3
     assert lib.msda_point_sample_backward(o.data_ptr(), x.data_ptr(), pc.data_ptr(), x.data_ptr(),
-                                          pc.data_ptr(), 1, 1, 2, 2, 1, _lib.BF16, 0, 0, None) == -3
+                                          pc.data_ptr(), None, 0, 1, 1, 2, 2, 1, _lib.BF16, 0, 0,
+                                          None) == -3

@@ -10,7 +10,7 @@ from pathlib import Path
 _PKG = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ.get("MSDA_LIBRARY", _PKG / "libmsda.so"))
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 # dtype codes of include/msda.h
 F32, F64, BF16, F16 = 0, 1, 2, 3
@@ -36,6 +36,7 @@ EXPORTS = (
     "msda_points_backward",
     "msda_point_sample_forward",
     "msda_point_sample_backward",
+    "msda_point_sample_workspace_bytes",
 )
 
 _lock = threading.Lock()
@@ -77,7 +78,9 @@ def _declare(lib: ctypes.CDLL) -> None:
     lib.msda_point_sample_forward.restype = c_int
     lib.msda_point_sample_forward.argtypes = [c_vp] * 3 + [c_int] * 8 + [c_vp]
     lib.msda_point_sample_backward.restype = c_int
-    lib.msda_point_sample_backward.argtypes = [c_vp] * 5 + [c_int] * 8 + [c_vp]
+    lib.msda_point_sample_backward.argtypes = [c_vp] * 6 + [c_sz] + [c_int] * 8 + [c_vp]
+    lib.msda_point_sample_workspace_bytes.restype = c_sz
+    lib.msda_point_sample_workspace_bytes.argtypes = [c_int] * 6
 
 
 def load() -> ctypes.CDLL:

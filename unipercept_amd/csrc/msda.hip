@@ -12,7 +12,7 @@ namespace {
 
 using namespace msda;
 
-constexpr int kAbiVersion = 3;
+constexpr int kAbiVersion = 4;
 
 inline size_t elem_size(int dtype) {
   switch (dtype) {
@@ -391,9 +391,17 @@ int msda_point_sample_forward(const void* input, const void* coords, void* out, 
   return launch_status();
 }
 
+size_t msda_point_sample_workspace_bytes(int N, int C, int H, int W, int P, int dtype) {
+  if (N < 1 || C < 1 || H < 1 || W < 1 || P < 1) return 0;
+  if (dtype != MSDA_F32 && dtype != MSDA_F64) return 0;
+  if (static_cast<int64_t>(N) * P > INT32_MAX / 2) return 0;
+  return sample_band_rows(H, W, 64 * 1024) > 0 ? sample_lists_bytes(N, P) : 0;
+}
+
 int msda_point_sample_backward(const void* grad_out, const void* input, const void* coords,
-                               void* grad_input, void* grad_coords, int N, int C, int H, int W,
-                               int P, int dtype, int mode, int align_corners, void* hip_stream) {
+                               void* grad_input, void* grad_coords, void* workspace,
+                               size_t workspace_bytes, int N, int C, int H, int W, int P,
+                               int dtype, int mode, int align_corners, void* hip_stream) {
   if (!grad_out || !input || !coords || !grad_input || !grad_coords) return MSDA_ENULL;
   if (N < 1 || C < 1 || H < 1 || W < 1 || P < 1) return MSDA_ESHAPE;
   if (static_cast<int64_t>(H) * W > INT32_MAX) return MSDA_ESHAPE;
@@ -425,6 +433,12 @@ int msda_point_sample_backward(const void* grad_out, const void* input, const vo
     band_blocks = sample_grid_blocks(bg);
   }
   const bool banded = band_rows > 0 && band_blocks <= INT32_MAX;
+  // point lists per band, when the caller brought the workspace for them
+  const size_t lists_need = msda_point_sample_workspace_bytes(N, C, H, W, P, dtype);
+  const bool listed = banded && lists_need > 0 && workspace != nullptr &&
+                      workspace_bytes >= lists_need && aligned(workspace, 4);
+  int* list = listed ? static_cast<int*>(workspace) : nullptr;
+  int* list_off = listed ? list + static_cast<size_t>(N) * 2 * P : nullptr;
   if (!banded) {
     err = hipMemsetAsync(grad_input, 0, static_cast<size_t>(N) * C * H * W * e, stream);
     if (err != hipSuccess) return static_cast<int>(err);
@@ -442,11 +456,15 @@ int msda_point_sample_backward(const void* grad_out, const void* input, const vo
 #define MSDA_SBAND(T)                                                                           \
   do {                                                                                          \
     const size_t lds = static_cast<size_t>(band_rows) * W * sizeof(double);                     \
+    if (listed)                                                                                 \
+      hipLaunchKernelGGL((point_band_lists_kernel<T>), dim3(static_cast<unsigned>(N)),          \
+                         dim3(1024), 0, stream, static_cast<const T*>(coords), list, list_off,  \
+                         H, P, band_rows, bg.per, mode, align_corners ? 1 : 0);                 \
     hipLaunchKernelGGL((point_sample_bwd_band_kernel<T>),                                       \
                        dim3(static_cast<unsigned>(band_blocks)), dim3(1024), lds, stream,       \
                        static_cast<const T*>(grad_out), static_cast<const T*>(coords),          \
-                       static_cast<T*>(grad_input), C, H, W, P, bg, band_rows, mode,            \
-                       align_corners ? 1 : 0);                                                  \
+                       static_cast<T*>(grad_input), list, list_off, C, H, W, P, bg, band_rows,  \
+                       mode, align_corners ? 1 : 0);                                            \
   } while (0)
   if (dtype == MSDA_F32) {
     if (banded) {

@@ -208,16 +208,88 @@ __global__ __launch_bounds__(256) void point_sample_bwd_kernel(
   }
 }
 
+// Rows a point touches: ya (weight wa) and yb (weight wb); yb == ya when there is only one.
+template <typename T>
+__device__ __forceinline__ void point_rows(T cy, int H, int mode, int align, int& ya, int& yb,
+                                           T& wa, T& wb) {
+  T my;
+  const T iy = border_coordinate<T>(cy, H, align, my);
+  if (mode == kSampleNearest) {
+    ya = yb = min(max(static_cast<int>(rint(iy)), 0), H - 1);
+    wa = 1;
+    wb = 0;
+  } else {
+    const T yf = floor(iy);
+    ya = static_cast<int>(yf);
+    yb = ya + 1;
+    wb = iy - yf;
+    wa = static_cast<T>(1) - wb;
+    if (yb >= H) {  // only when iy == H - 1: the row below is outside the map
+      yb = ya;
+      wb = 0;
+    }
+  }
+}
+
+constexpr int kMaxBands = 64;
+
+// Point lists per band of rows, one workgroup per sample: list[n][off[n][b] .. off[n][b + 1])
+// holds the points of sample n that touch band b (a point whose two rows straddle a band
+// boundary is listed in both).  `list` has 2 * P entries per sample, `off` kMaxBands + 1.
+// The band kernel then walks P / bands points instead of all P.
+template <typename T>
+__global__ __launch_bounds__(1024) void point_band_lists_kernel(
+    const T* __restrict__ coords, int* __restrict__ list, int* __restrict__ off, int H, int P,
+    int band_rows, int n_bands, int mode, int align) {
+  __shared__ int cnt[kMaxBands + 1];
+  const int64_t n = blockIdx.x;
+  const T* xy = coords + n * P * 2;
+  int* my_list = list + n * 2 * static_cast<int64_t>(P);
+  int* my_off = off + n * (kMaxBands + 1);
+  if (threadIdx.x <= kMaxBands) cnt[threadIdx.x] = 0;
+  __syncthreads();
+  for (int p = threadIdx.x; p < P; p += 1024) {
+    int ya, yb;
+    T wa, wb;
+    point_rows<T>(xy[2 * p + 1], H, mode, align, ya, yb, wa, wb);
+    const int ba = ya / band_rows, bb = yb / band_rows;
+    atomicAdd(&cnt[ba], 1);
+    if (bb != ba) atomicAdd(&cnt[bb], 1);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {  // exclusive scan of at most 64 counts; cnt becomes the cursor
+    int run = 0;
+    for (int b2 = 0; b2 < n_bands; ++b2) {
+      const int c = cnt[b2];
+      my_off[b2] = run;
+      cnt[b2] = run;
+      run += c;
+    }
+    my_off[n_bands] = run;
+  }
+  __syncthreads();
+  for (int p = threadIdx.x; p < P; p += 1024) {
+    int ya, yb;
+    T wa, wb;
+    point_rows<T>(xy[2 * p + 1], H, mode, align, ya, yb, wa, wb);
+    const int ba = ya / band_rows, bb = yb / band_rows;
+    my_list[atomicAdd(&cnt[ba], 1)] = p;
+    if (bb != ba) my_list[atomicAdd(&cnt[bb], 1)] = p;
+  }
+}
+
 // grad_input without global atomics: one workgroup owns a band of `band_rows` rows of one plane,
 // keeps it in LDS as doubles (ds_add_f64 runs ~10x faster than ds_add_f32 on gfx950 and the sum
-// is rounded once), walks ALL points of the sample and adds the corners that fall into its band,
-// then stores the band with plain coalesced stores: no memset, every element written once.  The
-// scattered global float atomics this replaces run at ~0.08 TB/s of added bytes when the 64
-// lanes of a wave hit 64 different lines, which is what random points do.
+// is rounded once), walks the points of its sample that touch the band (all points when no
+// lists were built) and adds their corners, then stores the band with plain coalesced stores: no
+// memset, every element written once.  The scattered global float atomics this replaces run at
+// ~0.08 TB/s of added bytes when the 64 lanes of a wave hit 64 different lines, which is what
+// random points do.
 template <typename T>
 __global__ __launch_bounds__(1024) void point_sample_bwd_band_kernel(
     const T* __restrict__ grad_out, const T* __restrict__ coords, T* __restrict__ grad_input,
-    int C, int H, int W, int P, SampleGrid grid, int band_rows, int mode, int align) {
+    const int* __restrict__ list, const int* __restrict__ off, int C, int H, int W, int P,
+    SampleGrid grid, int band_rows, int mode, int align) {
   extern __shared__ double band[];
   const SampleBlock blk = sample_block(grid);  // unit = plane (cper = 1), sub = band
   if (!blk.live) return;
@@ -229,27 +301,14 @@ __global__ __launch_bounds__(1024) void point_sample_bwd_band_kernel(
   __syncthreads();
   const T* go = grad_out + (n * C + c) * P;
   const T* xy = coords + n * P * 2;
-  for (int p = threadIdx.x; p < P; p += 1024) {
-    // rows first: most points miss the band
-    T my;
-    const T iy = border_coordinate<T>(xy[2 * p + 1], H, align, my);
+  const int* my_list = list ? list + n * 2 * static_cast<int64_t>(P) : nullptr;
+  const int e0 = list ? off[n * (kMaxBands + 1) + blk.sub] : 0;
+  const int e1 = list ? off[n * (kMaxBands + 1) + blk.sub + 1] : P;
+  for (int e = e0 + threadIdx.x; e < e1; e += 1024) {
+    const int p = list ? my_list[e] : e;
     int ya, yb;
     T wa, wb;
-    if (mode == kSampleNearest) {
-      ya = yb = min(max(static_cast<int>(rint(iy)), 0), H - 1);
-      wa = 1;
-      wb = 0;
-    } else {
-      const T yf = floor(iy);
-      ya = static_cast<int>(yf);
-      yb = ya + 1;
-      wb = iy - yf;
-      wa = static_cast<T>(1) - wb;
-      if (yb >= H) {  // only when iy == H - 1: the row below is outside the map
-        yb = ya;
-        wb = 0;
-      }
-    }
+    point_rows<T>(xy[2 * p + 1], H, mode, align, ya, yb, wa, wb);
     const bool in_a = ya >= y_lo && ya < y_hi, in_b = yb >= y_lo && yb < y_hi && yb != ya;
     if (!in_a && !in_b) continue;
     T mx;
@@ -307,8 +366,7 @@ inline bool make_sample_grid(int N, int C, int P, SampleGrid* g, int64_t* blocks
 
 // Band plan of the atomic-free grad_input kernel: rows per band so that a band of doubles fits
 // `lds_bytes`, or 0 when the map is too wide or would need more than kMaxBands bands (every
-// band's workgroup walks all points of its sample).
-constexpr int kMaxBands = 64;
+// band's workgroup walks all points of its sample when no point lists were built).
 inline int sample_band_rows(int H, int W, size_t lds_bytes) {
   const int64_t cells = static_cast<int64_t>(lds_bytes / sizeof(double));
   if (W > cells) return 0;
@@ -318,6 +376,12 @@ inline int sample_band_rows(int H, int W, size_t lds_bytes) {
   if (bands > kMaxBands) return 0;
   // even out the bands (the last one would otherwise be short)
   return (H + bands - 1) / bands;
+}
+
+// bytes of the band point lists of one backward call: per sample 2 * P point indices and
+// kMaxBands + 1 offsets
+inline size_t sample_lists_bytes(int N, int P) {
+  return (static_cast<size_t>(N) * 2 * P + static_cast<size_t>(N) * (kMaxBands + 1)) * sizeof(int);
 }
 
 }  // namespace msda

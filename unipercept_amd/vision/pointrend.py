@@ -98,9 +98,12 @@ def point_sample_bwd(grad_out: torch.Tensor, input: torch.Tensor, point_coords: 
     grad_input = torch.empty_like(input_w)
     grad_coords = torch.empty_like(coords_w)
     with torch.cuda.device_of(input):
+        nbytes = lib.msda_point_sample_workspace_bytes(n, c, h, w, p, _DTYPE_CODE[work])
+        workspace = torch.empty(nbytes, dtype=torch.uint8, device=input.device) if nbytes else None
         rc = lib.msda_point_sample_backward(
             grad_out_w.data_ptr(), input_w.data_ptr(), coords_w.data_ptr(), grad_input.data_ptr(),
-            grad_coords.data_ptr(), n, c, h, w, p, _DTYPE_CODE[work], mode, int(align_corners),
+            grad_coords.data_ptr(), workspace.data_ptr() if nbytes else None, nbytes,
+            n, c, h, w, p, _DTYPE_CODE[work], mode, int(align_corners),
             torch.cuda.current_stream(input.device).cuda_stream,
         )
     _lib.check(rc, "msda_point_sample_backward")
