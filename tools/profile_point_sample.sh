@@ -16,13 +16,13 @@ import csv, glob, json, sys, collections
 out = sys.argv[1]
 res = {"bench": json.load(open(f"{out}/bench.json")), "kernels": {}}
 for r in csv.DictReader(open(glob.glob(f"{out}/kt/*/*_kernel_stats.csv")[0])):
-    if "point_sample" in r["Name"]:
+    if "msda::point_" in r["Name"]:
         res["kernels"][r["Name"]] = {"calls": int(r["Calls"]), "avg_ms": float(r["AverageNs"]) / 1e6}
 for name in ("FETCH_SIZE", "WRITE_SIZE", "TCC_HIT_sum"):
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for f in glob.glob(f"{out}/pmc_{name}/*/*_counter_collection.csv"):
         for r in csv.DictReader(open(f)):
-            if "point_sample" in r["Kernel_Name"]:
+            if "msda::point_" in r["Kernel_Name"]:
                 acc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k, cs in acc.items():
         for c, v in cs.items():

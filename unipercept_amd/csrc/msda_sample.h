@@ -154,10 +154,14 @@ __global__ __launch_bounds__(256) void point_sample_fwd_kernel(
   const int64_t plane = static_cast<int64_t>(H) * W;
   for (int c = c0; c < c1; ++c) {
     const T* src = input + (n * C + c) * plane;
+    // all four loads go out together (every offset lies inside the map); a corner that does
+    // not take part is dropped afterwards, whatever its value
+    CT v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = static_cast<CT>(Elem<T>::load(src + f.off[k]));
     CT acc = 0;
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
-      if (f.valid >> k & 1u) acc += static_cast<CT>(Elem<T>::load(src + f.off[k])) * f.w[k];
+    for (int k = 0; k < 4; ++k) acc += (f.valid >> k & 1u) ? v[k] * f.w[k] : static_cast<CT>(0);
     Elem<T>::store(out + (n * C + c) * P + p, acc);
   }
 }
@@ -185,13 +189,15 @@ __global__ __launch_bounds__(256) void point_sample_bwd_kernel(
       const T* src = input + (n * C + c) * plane;
       T* dst = grad_input + (n * C + c) * plane;
       const T g = grad_out[(n * C + c) * P + p];
+      T v[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] = src[f.off[k]];  // together; offsets are always inside
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         if (f.valid >> k & 1u) {
-          const T v = src[f.off[k]];
           if constexpr (SCATTER) atomicAdd(dst + f.off[k], f.w[k] * g);
-          sx += v * f.dwx[k] * g;
-          sy += v * f.dwy[k] * g;
+          sx += v[k] * f.dwx[k] * g;
+          sy += v[k] * f.dwy[k] * g;
         }
       }
     }
