@@ -34,7 +34,7 @@ CASES = {
     # gradcheck head dims (test_nn_layers_deform_attn.py:125), small ones
     "d30": (1, 2, 30, 2, [(32, 16), (16, 8)], 2, "unit"),
     "d71": (1, 2, 71, 3, [(6, 4), (3, 2)], 2, "wide"),
-    # shrunken BASELINE configs (encoder style, Lq = S)
+    # shrunken benchmark configurations (encoder style, Lq = S)
     "cfg2_small": (2, 4, 32, None, [(4, 8), (2, 4), (1, 2)], 4, "wide"),
     "cfg4_small": (1, 8, 32, None, [(8, 8), (4, 4), (2, 2), (1, 1)], 4, "wide"),
     "cfg5_small": (2, 2, 32, None, [(4, 8), (2, 4), (1, 2), (1, 1)], 8, "wide"),

@@ -1,4 +1,4 @@
-"""Full-size (BASELINE shapes) checks through size-independent properties; the CPU oracle would
+"""Full-size (benchmark shapes) checks through size-independent properties; the CPU oracle would
 take minutes at these sizes, so parity at full size rests on identities the op must satisfy."""
 
 from __future__ import annotations

@@ -10,7 +10,7 @@ from conftest import golden_cases, level_start_index, load_golden, make_inputs
 
 pytestmark = pytest.mark.gpu
 
-# BASELINE tolerances for fp32: max-abs 1e-4 forward, 1e-3 backward.  The golden inputs have
+# Stated tolerances for fp32: max-abs 1e-4 forward, 1e-3 backward.  The golden inputs have
 # |value| <= 0.01 and |grad_out| ~ 1, so the observed errors sit orders of magnitude below.
 FWD_ATOL_F32 = 1e-4
 BWD_ATOL_F32 = 1e-3
