@@ -61,12 +61,14 @@ __global__ __launch_bounds__(256) void fwd_generic_kernel(
         const CT y = static_cast<CT>(Elem<LT>::load(loc_p + 2 * i + 1));
         const CT a = static_cast<CT>(Elem<LT>::load(attn_p + i));
         const Footprint<CT> f = footprint<CT>(x, y, H, W);
-        if (f.any && act) {
+        if (act) {
+          // the four loads go out together: every corner address is clamped into the level; a
+          // corner that does not take part is dropped afterwards, whatever was loaded
+          CT v[4];
 #pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            if (f.valid[k])
-              acc += a * f.w[k] * static_cast<CT>(Elem<VT>::load(base + f.pix[k] * row));
-          }
+          for (int k = 0; k < 4; ++k) v[k] = static_cast<CT>(Elem<VT>::load(base + f.pix[k] * row));
+#pragma unroll
+          for (int k = 0; k < 4; ++k) acc += f.valid[k] ? a * f.w[k] * v[k] : static_cast<CT>(0);
         }
       }
     }
@@ -111,11 +113,15 @@ __global__ __launch_bounds__(256) void bwd_generic_kernel(
       if (f.any) {
         for (int c = lane; c < D; c += G) {
           const CT g = static_cast<CT>(Elem<VT>::load(go_p + c));
+          CT v[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k)  // together; clamped addresses, see the forward
+            v[k] = static_cast<CT>(Elem<VT>::load(value + base + f.pix[k] * row + c));
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
             if (f.valid[k]) {
               const int64_t off = base + f.pix[k] * row + c;
-              dot[k] += g * static_cast<CT>(Elem<VT>::load(value + off));
+              dot[k] += g * v[k];
               if (SCATTER && live) atomicAdd(grad_value_acc + off, static_cast<GT>(a * f.w[k] * g));
             }
           }
