@@ -374,7 +374,7 @@ int msda_point_sample_forward(const void* input, const void* coords, void* out, 
   if (!aligned(input, e) || !aligned(coords, e) || !aligned(out, e)) return MSDA_EALIGN;
   SampleGrid g;
   int64_t blocks;
-  if (!make_sample_grid(N, C, P, &g, &blocks)) return MSDA_ESHAPE;
+  if (!make_sample_grid(N, C, P, &g, &blocks, 256 * kSamplePPT)) return MSDA_ESHAPE;
   hipStream_t stream = static_cast<hipStream_t>(hip_stream);
 #define MSDA_SF(T)                                                                              \
   hipLaunchKernelGGL((point_sample_fwd_kernel<T>), dim3(static_cast<unsigned>(blocks)),         \

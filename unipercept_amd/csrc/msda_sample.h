@@ -138,6 +138,11 @@ __device__ __forceinline__ SampleBlock sample_block(const SampleGrid& g) {
 
 inline int64_t sample_grid_blocks(const SampleGrid& g) { return (g.units + 7) / 8 * 8 * g.per; }
 
+#ifndef MSDA_SAMPLE_PPT
+#define MSDA_SAMPLE_PPT 2
+#endif
+constexpr int kSamplePPT = MSDA_SAMPLE_PPT;  // points per thread of the forward (loads of all in flight together)
+
 template <typename T>
 __global__ __launch_bounds__(256) void point_sample_fwd_kernel(
     const T* __restrict__ input, const T* __restrict__ coords, T* __restrict__ out, int C, int H,
@@ -145,24 +150,36 @@ __global__ __launch_bounds__(256) void point_sample_fwd_kernel(
   using CT = typename Elem<T>::compute_t;
   const SampleBlock blk = sample_block(grid);
   const int64_t n = blk.n;
-  const int p = blk.sub * 256 + threadIdx.x;
-  if (!blk.live || p >= P) return;
-  const T* xy = coords + (n * P + p) * 2;
-  const BorderPoint<CT> f = border_point<CT>(static_cast<CT>(Elem<T>::load(xy)),
-                                             static_cast<CT>(Elem<T>::load(xy + 1)), H, W, mode, align);
+  if (!blk.live) return;
+  int p[kSamplePPT];
+  BorderPoint<CT> f[kSamplePPT];
+#pragma unroll
+  for (int u = 0; u < kSamplePPT; ++u) {
+    p[u] = blk.sub * (256 * kSamplePPT) + u * 256 + threadIdx.x;
+    const int pc = min(p[u], P - 1);  // a slot past the end redoes the last point (not stored)
+    const T* xy = coords + (n * P + pc) * 2;
+    f[u] = border_point<CT>(static_cast<CT>(Elem<T>::load(xy)),
+                            static_cast<CT>(Elem<T>::load(xy + 1)), H, W, mode, align);
+  }
   const int c0 = blk.cs * grid.cper, c1 = min(C, c0 + grid.cper);
   const int64_t plane = static_cast<int64_t>(H) * W;
   for (int c = c0; c < c1; ++c) {
     const T* src = input + (n * C + c) * plane;
-    // all four loads go out together (every offset lies inside the map); a corner that does
-    // not take part is dropped afterwards, whatever its value
-    CT v[4];
+    // all loads go out together (every offset lies inside the map); a corner that does not
+    // take part is dropped afterwards, whatever its value
+    CT v[kSamplePPT][4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) v[k] = static_cast<CT>(Elem<T>::load(src + f.off[k]));
-    CT acc = 0;
+    for (int u = 0; u < kSamplePPT; ++u)
 #pragma unroll
-    for (int k = 0; k < 4; ++k) acc += (f.valid >> k & 1u) ? v[k] * f.w[k] : static_cast<CT>(0);
-    Elem<T>::store(out + (n * C + c) * P + p, acc);
+      for (int k = 0; k < 4; ++k) v[u][k] = static_cast<CT>(Elem<T>::load(src + f[u].off[k]));
+#pragma unroll
+    for (int u = 0; u < kSamplePPT; ++u) {
+      CT acc = 0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        acc += (f[u].valid >> k & 1u) ? v[u][k] * f[u].w[k] : static_cast<CT>(0);
+      if (p[u] < P) Elem<T>::store(out + (n * C + c) * P + p[u], acc);
+    }
   }
 }
 
@@ -356,8 +373,9 @@ __global__ __launch_bounds__(1024) void point_sample_bwd_band_kernel(
 
 // Channels per slice: enough slices to fill the chip when there are few points, whole samples per
 // thread when there are many (the footprint is then computed once per point).
-inline bool make_sample_grid(int N, int C, int P, SampleGrid* g, int64_t* blocks) {
-  const int pblocks = (P + 255) / 256;
+inline bool make_sample_grid(int N, int C, int P, SampleGrid* g, int64_t* blocks,
+                             int points_per_block = 256) {
+  const int pblocks = (P + points_per_block - 1) / points_per_block;
   int cper = C;
   // aim for >= 2048 workgroups; never fewer than 8 channels per slice unless C is smaller
   while (cper > 8 && static_cast<int64_t>(N) * pblocks * ((C + cper - 1) / cper) < 2048) cper = (cper + 1) / 2;
