@@ -35,14 +35,14 @@ from unipercept_amd import harness  # noqa: E402
 HBM_PEAK = 8.0e12  # bytes/s, MI355X spec
 
 
-def cpu_baseline(threads: int) -> dict:
+def cpu_baseline(threads: int, dist_name: str = "R") -> dict:
     """The pure-PyTorch grid_sample oracle, timed on this host's cores on a bounded sample:
     the CPU-reference workload (batch 1, 512x1024, 3 levels, 8 heads, 4 points, fp32)."""
     from oracle import grid_sample_ref
 
     w = harness.WORKLOADS["cpuref_512x1024_fp32_b1"]
     torch.set_num_threads(threads)
-    value, shapes, lsi, loc, attn, grad_out = harness.synth_inputs(w, "cpu", seed=1234, dist="U")
+    value, shapes, lsi, loc, attn, grad_out = harness.synth_inputs(w, "cpu", seed=1234, dist=dist_name)
     levels = shapes.tolist()
 
     def run():
@@ -68,7 +68,9 @@ def cpu_baseline(threads: int) -> dict:
         "cores": threads,
         "kind": "port",
         "sample": f"{w.name}: {pts} sampled points fwd+bwd, median of {len(times)} runs "
-        f"({med * 1e3:.1f} ms each), torch grid_sample formulation, {threads} threads",
+        f"({med * 1e3:.1f} ms each), torch grid_sample formulation, location distribution "
+        f"{dist_name}, {threads} threads (os.cpu_count() = {os.cpu_count()}, OMP_NUM_THREADS = "
+        f"{os.environ.get('OMP_NUM_THREADS', 'unset')})",
     }
 
 
@@ -270,6 +272,10 @@ def main() -> None:
                     help="time the whole MSDeformAttn layer (the four projections on PyTorch-ROCm GEMMs "
                     "around the op) with its real parameter gradients in the all-reduced bucket; "
                     "sampling locations are then the layer's own (ring-initialised offsets)")
+    ap.add_argument("--comm", default="inline", choices=["inline", "overlap"],
+                    help="multi-rank runs: issue the gradient all-reduce on the compute stream right "
+                    "after the backward (inline, default) or on a side stream overlapped with the "
+                    "next step (overlap)")
     ap.add_argument("--no-head-major", action="store_true",
                     help="gather from the (N,S,M,D) value as given instead of a per-head copy")
     args = ap.parse_args()
@@ -279,12 +285,15 @@ def main() -> None:
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit(
-                f"--gpus {args.gpus} needs one rank per GPU: launch with "
-                f"`python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} "
-                "--master-addr 127.0.0.1 --master-port P bench.py ...`"
-            )
+        if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+            # invoked plainly: this process becomes the launcher (it has not touched the GPU and
+            # never will) and starts one rank per GPU; rank 0's JSON line goes to the inherited
+            # stdout
+            visible = torch.cuda.device_count()  # counting devices does not initialise the GPU
+            if visible < args.gpus:
+                raise SystemExit(f"--gpus {args.gpus} but only {visible} GPU(s) are visible")
+            os.dup2(_RESULT_OUT.fileno(), 1)  # the children inherit the real stdout
+            raise SystemExit(harness.launch_ranks(str(Path(__file__).resolve()), sys.argv[1:], args.gpus))
         raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no GPU visible); there is no CPU fallback")
@@ -381,9 +390,16 @@ def main() -> None:
         if i is not None:
             ev[i][2].record()
         if distributed:
+            reduce_bucket()
+
+    def reduce_bucket() -> None:
+        if args.comm == "overlap":
+            # the gradient bucket of this step is reduced while the next step computes
             comm_stream.wait_stream(torch.cuda.current_stream(device))
             with torch.cuda.stream(comm_stream):
                 bucket.all_reduce()
+        else:
+            bucket.all_reduce()  # behind the backward, on the compute stream
 
     def step(i: int | None) -> None:
         if layer is not None:
@@ -403,10 +419,7 @@ def main() -> None:
             ev[i][2].record()
         del out, v
         if bucket is not None:
-            # the gradient bucket of this step is reduced while the next step computes
-            comm_stream.wait_stream(torch.cuda.current_stream(device))
-            with torch.cuda.stream(comm_stream):
-                bucket.all_reduce()
+            reduce_bucket()
 
     def fence() -> None:
         torch.cuda.synchronize(device)
@@ -488,7 +501,9 @@ def main() -> None:
                 "collective": None
                 if not distributed
                 else f"all_reduce(sum)/world of one flat fp32 bucket of {bucket.flat.numel()} "
-                "layer-parameter gradients per step, RCCL, side stream",
+                "layer-parameter gradients per step, RCCL, "
+                + ("side stream, overlapped with the next step" if args.comm == "overlap"
+                   else "on the compute stream behind the backward"),
             },
             "roofline": {
                 "bound": "hbm",
@@ -513,8 +528,10 @@ def main() -> None:
             },
         }
         if not args.no_cpu_baseline and world == 1:
-            threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
-            line["cpu_baseline"] = cpu_baseline(threads)
+            # every core this process may use: the box caps a job's share through OMP_NUM_THREADS
+            # (os.cpu_count() shows the whole machine there); without the cap, all of them
+            threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or (os.cpu_count() or 1)
+            line["cpu_baseline"] = cpu_baseline(threads, args.dist)
         emit_result(line)
 
     if distributed:

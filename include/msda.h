@@ -75,6 +75,10 @@ enum {
    * ignored.  Weights are used as given (no softmax), as that test compares against
    * `reference.deform_attn` with the same weights.  Where msda_packed_points_supported() says so. */
   MSDA_FLAG_PACKED_POINTS = 16,
+  /* msda_backward / msda_backward_workspace_bytes: ignore `shapes_host`, i.e. cut grad_value into
+   * runs of the flattened sequence even when the level shapes are known on the host (for A/B
+   * measurements and tests of that geometry). */
+  MSDA_FLAG_TILE_1D = 32,
 };
 
 /* Library ABI version (bumped when a signature changes or entry points are added). */
@@ -151,8 +155,9 @@ size_t msda_backward_workspace_bytes(int N, int S, int M, int D, int Lq, int L, 
  *
  * `shapes_host` is optional (NULL allowed): a HOST copy of the L (H, W) pairs in `shapes_dev`.
  * With it, and when `lsi_dev` is the exclusive prefix sum of H*W (the usual pyramid), the binned
- * scatter cuts grad_value into 16-pixel-wide 2-D patches of a level instead of runs of the
- * flattened sequence, which saves about a quarter of its record traffic.  It must match
+ * scatter cuts grad_value into 8 x 8 pixel patches of a level instead of runs of the
+ * flattened sequence, which saves about a third of its record traffic (1.27 records per sampled
+ * point instead of about 2 on a 1024 x 2048 pyramid).  It must match
  * `shapes_dev`; a table that disagrees gives undefined grad_value contents (never an
  * out-of-bounds access).  The pointer is only read during the call.
  */
@@ -174,21 +179,25 @@ int msda_backward(const void* grad_out, const void* value, const int64_t* shapes
  * `unipercept.nn.layers.deform_attn` is imported at
  * tests/unipercept/nn/layers/test_nn_layers_deform_attn.py:6-10 only); this follows the
  * Deformable-DETR / Mask2Former pixel-decoder convention its models use.  All tensors have
- * `dtype` (F32, BF16 or F16); `raw` and `packed` must be 16-byte aligned and may not overlap.
+ * `raw` has `dtype_raw` (F32, BF16 or F16); `ref_points` and `packed` have `dtype_packed`, which
+ * is `dtype_raw` or F32 (a 16-bit projection output with full-resolution locations and weights:
+ * a bf16 location near 1.0 moves in steps of 1/256, a whole pixel on a 256-wide level).  `raw`
+ * and `packed` must be 16-byte aligned and may not overlap.
  */
 int msda_points_forward(const void* raw, const void* ref_points, const int64_t* shapes_dev,
-                        void* packed, int N, int Lq, int M, int L, int P, int dtype,
-                        void* hip_stream);
+                        void* packed, int N, int Lq, int M, int L, int P, int dtype_raw,
+                        int dtype_packed, void* hip_stream);
 
 /*
  * Gradient of msda_points_forward with respect to `raw`, from the gradient of `packed` and
  * `packed` itself (its weights part):  d(dx, dy) = d(x, y) / (W_l, H_l),
  * d logit_i = w_i * (g_i - sum_k w_k g_k).  The gradient of `ref_points`, where a caller needs
- * it, is the sum of d(x, y) over heads and points.
+ * it, is the sum of d(x, y) over heads and points.  `grad_packed` and `packed` have
+ * `dtype_packed`, `grad_raw` has `dtype_raw` (combinations as for msda_points_forward).
  */
 int msda_points_backward(const void* grad_packed, const void* packed, const int64_t* shapes_dev,
-                         void* grad_raw, int N, int Lq, int M, int L, int P, int dtype,
-                         void* hip_stream);
+                         void* grad_raw, int N, int Lq, int M, int L, int P, int dtype_raw,
+                         int dtype_packed, void* hip_stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Point sampling (PointRend): the same bilinear gather on one NCHW map with border padding.

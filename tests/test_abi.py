@@ -175,16 +175,18 @@ def test_packed_points_flag_arguments():
 def test_points_epilogue_argument_errors():
     lib = _lib.load()
 
-    def fwd(raw=FAKE, ref=FAKE, shapes=FAKE, packed=FAKE, dims=(1, 5, 2, 2, 2), dtype=0):
-        return lib.msda_points_forward(raw, ref, shapes, packed, *dims, dtype, None)
+    def fwd(raw=FAKE, ref=FAKE, shapes=FAKE, packed=FAKE, dims=(1, 5, 2, 2, 2), dtype=0, pdtype=None):
+        return lib.msda_points_forward(raw, ref, shapes, packed, *dims, dtype, dtype if pdtype is None else pdtype, None)
 
-    def bwd(gp=FAKE, packed=FAKE, shapes=FAKE, graw=FAKE, dims=(1, 5, 2, 2, 2), dtype=0):
-        return lib.msda_points_backward(gp, packed, shapes, graw, *dims, dtype, None)
+    def bwd(gp=FAKE, packed=FAKE, shapes=FAKE, graw=FAKE, dims=(1, 5, 2, 2, 2), dtype=0, pdtype=None):
+        return lib.msda_points_backward(gp, packed, shapes, graw, *dims, dtype, dtype if pdtype is None else pdtype, None)
 
     assert fwd(raw=None) == -1 and fwd(ref=None) == -1 and bwd(graw=None) == -1
     assert fwd(dims=(0, 5, 2, 2, 2)) == -2 and bwd(dims=(1, 0, 2, 2, 2)) == -2
     assert fwd(dims=(1, 5, 2, 17, 2)) == -7 and bwd(dims=(1, 5, 2, 8, 32)) == -7
     assert fwd(dtype=_lib.F64) == -3 and bwd(dtype=9) == -3
+    # the packed side is raw's type or fp32, nothing else
+    assert fwd(dtype=_lib.F32, pdtype=_lib.BF16) == -3 and bwd(dtype=_lib.BF16, pdtype=_lib.F16) == -3
     assert fwd(raw=FAKE + 8) == -4 and bwd(graw=FAKE + 4) == -4  # 16-byte alignment
     assert fwd(shapes=FAKE + 4) == -4
 

@@ -96,3 +96,36 @@ def test_two_rank_gradient_average_equals_full_batch(tmp_path):
     loss.backward()
     want = torch.cat([p.grad.reshape(-1) for p in layer.parameters()])
     assert torch.allclose(got[0].double(), want, rtol=1e-5, atol=1e-8)
+
+
+@pytest.mark.timeout(180)
+def test_launcher_spawns_one_rank_per_process(tmp_path):
+    """`python bench.py --gpus N` invoked plainly becomes a launcher (harness.launch_ranks): N
+    children with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, rank 0's line on the inherited
+    stdout, a failing rank fails the launch.  Rehearsed here with two gloo ranks."""
+    import json
+    import subprocess
+
+    probe = str(ROOT / "tests" / "_rank_probe.py")
+    code = (
+        "import sys; sys.path.insert(0, %r); from unipercept_amd import harness; "
+        "sys.exit(harness.launch_ranks(%r, sys.argv[1:], 2, timeout=120))" % (str(ROOT), probe)
+    )
+    ok = subprocess.run([sys.executable, "-c", code, "--steps", "3"], capture_output=True, text=True, timeout=170)
+    assert ok.returncode == 0, ok.stderr[-2000:]
+    lines = [ln for ln in ok.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec == {"world": 2, "sum": 3.0, "argv": ["--steps", "3"]}
+    bad = subprocess.run([sys.executable, "-c", code, "--fail-rank", "1"], capture_output=True, text=True, timeout=170)
+    assert bad.returncode == 3
+
+
+def test_bench_refuses_more_ranks_than_gpus():
+    """Without GPUs the plain `--gpus 2` invocation ends with a clear message (no launch)."""
+    import subprocess
+
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("two GPUs visible")
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=170)
+    assert r.returncode != 0 and "GPU(s) are visible" in r.stderr

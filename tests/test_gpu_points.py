@@ -30,6 +30,40 @@ CASES = {
 }
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("case", ["enc_L3P4", "odd_L3P3"])
+def test_points_16bit_raw_with_fp32_reference_points(case, dtype):
+    """A 16-bit projection output next to fp32 reference points: locations and weights come out
+    in fp32 (computed in fp32 from the rounded offsets and logits), the gradient of `raw` in the
+    16-bit type."""
+    from unipercept_amd.deform_attn import SamplingPointsFunction
+
+    n, lq, m, levels, p = CASES[case]
+    g = torch.Generator(device="cuda").manual_seed(9)
+    shapes = torch.as_tensor(levels, dtype=torch.long, device="cuda")
+    l = len(levels)
+    raw = (torch.randn(n, lq, m, 3 * l * p, generator=g, device="cuda") * 3).to(dtype)
+    ref = torch.rand(n, lq, l, 2, generator=g, device="cuda")
+    grad = torch.randn(n, lq, m, 3 * l * p, generator=g, device="cuda")
+    raw_a = raw.clone().requires_grad_(True)
+    ref_a = ref.clone().requires_grad_(True)
+    got = SamplingPointsFunction.apply(raw_a, ref_a, shapes)
+    assert got.dtype == torch.float32 and raw_a.dtype == dtype
+    got.backward(grad)
+    assert raw_a.grad.dtype == dtype and ref_a.grad.dtype == torch.float32
+    raw_b = raw.double().requires_grad_(True)
+    ref_b = ref.double().requires_grad_(True)
+    want = _torch_points(raw_b, ref_b, shapes)
+    want.backward(grad.double())
+    rel16 = {torch.bfloat16: 2**-8, torch.float16: 2**-10}[dtype]
+    for name, a, b, rel in (
+        ("packed", got, want, 2e-6), ("grad_raw", raw_a.grad, raw_b.grad, rel16),
+        ("grad_ref", ref_a.grad, ref_b.grad, 2e-6),
+    ):
+        err = (a.double() - b).abs().max().item()
+        assert err / (b.abs().max().item() + 1e-30) <= rel, (name, err)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("case", sorted(CASES))
 def test_points_forward_backward_match_torch(case, dtype):
@@ -102,6 +136,47 @@ def test_fused_layer_matches_unfused():
     for x, y in zip(a, b):
         scale = y.abs().max().item() + 1e-30
         assert (x - y).abs().max().item() / scale <= 2e-4
+
+
+def test_fused_layer_keeps_fp32_locations_under_autocast():
+    """Under bf16 autocast the projections run in bf16; the fused path must still hand the
+    kernels fp32 locations and weights (a bf16 location near 1.0 has a resolution of 1/256, a
+    pixel on the 256-wide level used here).  Both routes against an fp32 run of the same layer:
+    the fused one may not be further off than the unfused one (plus rounding noise)."""
+    from unipercept_amd.deform_attn import MSDeformAttn, _function
+
+    torch.manual_seed(5)
+    levels = [(64, 256), (32, 128), (16, 64)]
+    shapes = torch.as_tensor(levels, dtype=torch.long, device="cuda")
+    lsi = torch.cat((shapes.new_zeros((1,)), shapes.prod(1).cumsum(0)[:-1]))
+    s = int(shapes.prod(1).sum())
+    layer = MSDeformAttn(d_model=256, n_levels=3, n_heads=8, n_points=4).cuda()
+    torch.nn.init.normal_(layer.sampling_offsets.weight, std=0.02)
+    feats = torch.randn(1, s, 256, device="cuda")
+    ref = torch.rand(1, s, 3, 2, device="cuda") * 0.2 + 0.8  # near 1.0: coarsest bf16 steps
+    seen = {}
+    orig = _function._ops.ms_flash_attn_fwd
+
+    def spy(value, shapes_, lsi_, packed, flags):
+        seen["packed_dtype"], seen["value_dtype"] = packed.dtype, value.dtype
+        return orig(value, shapes_, lsi_, packed, flags)
+
+    want = layer(feats, ref, feats, shapes, lsi)
+    outs = {}
+    for fused in (True, False):
+        layer.fused_points = fused
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            if fused:
+                _function._ops.ms_flash_attn_fwd = spy
+            try:
+                outs[fused] = layer(feats, ref, feats, shapes, lsi).float()
+            finally:
+                _function._ops.ms_flash_attn_fwd = orig
+    assert seen == {"packed_dtype": torch.float32, "value_dtype": torch.bfloat16}
+    scale = want.abs().max().item()
+    err_fused = (outs[True] - want).abs().max().item() / scale
+    err_unfused = (outs[False] - want).abs().max().item() / scale
+    assert err_fused <= 2.0**-5 and err_fused <= err_unfused * 1.5 + 2.0**-8, (err_fused, err_unfused)
 
 
 def test_encoder_stack_hip_matches_oracle_injected():

@@ -81,6 +81,35 @@ def test_backward_flags(monkeypatch):
     assert _function.forward_flags() == _lib.FLAG_GENERIC
 
 
+def test_deterministic_mode_has_a_work_limit(monkeypatch):
+    """torch.use_deterministic_algorithms(True) routes small problems to the reproducible path;
+    at benchmark sizes (where that path would run for hours) it raises like a PyTorch op without
+    a deterministic kernel, or warns and keeps the binned path under warn_only."""
+    for k in ("MSDA_FORCE_GENERIC", "MSDA_DETERMINISTIC", "MSDA_ATOMIC_SCATTER", "MSDA_TILE_1D"):
+        monkeypatch.delenv(k, raising=False)
+    value, shapes, lsi, loc, attn, _ = _small()
+    big_value = torch.empty((8, 43008, 8, 32), device="meta")
+    big_loc = torch.empty((8, 43008, 8, 3, 4, 2), device="meta")
+    was, was_warn = torch.are_deterministic_algorithms_enabled(), torch.is_deterministic_algorithms_warn_only_enabled()
+    try:
+        torch.use_deterministic_algorithms(True)
+        assert _function.backward_flags(value, loc) == _lib.FLAG_DETERMINISTIC
+        with pytest.raises(RuntimeError, match="deterministic"):
+            _function.backward_flags(big_value, big_loc)
+        torch.use_deterministic_algorithms(True, warn_only=True)
+        with pytest.warns(UserWarning, match="deterministic"):
+            assert _function.backward_flags(big_value, big_loc) == 0
+        monkeypatch.setenv("MSDA_DETERMINISTIC", "1")  # explicit request: honoured at any size
+        assert _function.backward_flags(big_value, big_loc) == _lib.FLAG_DETERMINISTIC
+        monkeypatch.setenv("MSDA_DETERMINISTIC", "0")
+        assert _function.backward_flags(big_value, big_loc) == 0
+    finally:
+        torch.use_deterministic_algorithms(was, warn_only=was_warn)
+    monkeypatch.delenv("MSDA_DETERMINISTIC")
+    monkeypatch.setenv("MSDA_TILE_1D", "1")
+    assert _function.backward_flags(value, loc) == _lib.FLAG_TILE_1D
+
+
 def test_fake_kernels_give_shapes_without_running():
     value, shapes, lsi, loc, attn, grad_out = _small()
     to_meta = lambda t: t.to("meta")

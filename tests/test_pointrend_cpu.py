@@ -118,6 +118,27 @@ def test_sample_refuses_cpu_and_bad_arguments():
         pointrend.sample(src, pts.double())
 
 
+@pytest.mark.parametrize("n,c,p", [(0, 3, 5), (2, 0, 5), (2, 3, 0), (0, 0, 0)])
+def test_sample_of_nothing_is_empty_like_grid_sample(n, c, p):
+    """No samples, channels or points (a mask loss on a batch without instances): an empty
+    (N, C, P) result and zero-sized / zero gradients, exactly as grid_sample gives; no launch, so
+    this also holds for CPU tensors."""
+    src = torch.rand(n, c, 4, 6, requires_grad=True)
+    pts = torch.rand(n, p, 2, requires_grad=True)
+    out = pointrend.sample(src, pts)
+    want = torch.nn.functional.grid_sample(
+        src, 2 * pts.unsqueeze(2) - 1, padding_mode="border", align_corners=False
+    ).squeeze(3)
+    assert out.shape == want.shape == (n, c, p) and out.dtype == want.dtype
+    out.sum().backward()
+    assert src.grad.shape == src.shape and pts.grad.shape == pts.shape
+    assert float(src.grad.abs().sum()) == 0.0 and float(pts.grad.abs().sum()) == 0.0
+    grid = pointrend.sample(src, torch.rand(n, 0, 7, 2))
+    assert grid.shape == (n, c, 0, 7)
+    with pytest.raises(ValueError):
+        pointrend.sample(torch.rand(1, 1, 0, 4), torch.rand(1, 3, 2))
+
+
 def test_importance_sampling_host_logic(monkeypatch):
     # tests/unipercept/vision/test_pointrend.py:51-74 of the reference, with the sampler replaced
     # by the oracle (the HIP sampler needs a GPU; the GPU suite runs the same case through it)

@@ -10,7 +10,7 @@ from pathlib import Path
 _PKG = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ.get("MSDA_LIBRARY", _PKG / "libmsda.so"))
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 # dtype codes of include/msda.h
 F32, F64, BF16, F16 = 0, 1, 2, 3
@@ -19,6 +19,7 @@ FLAG_GENERIC = 2
 FLAG_ATOMIC_SCATTER = 4
 FLAG_VALUE_HEAD_MAJOR = 8
 FLAG_PACKED_POINTS = 16
+FLAG_TILE_1D = 32
 SAMPLE_BILINEAR, SAMPLE_NEAREST = 0, 1
 
 # every symbol include/msda.h declares
@@ -70,11 +71,10 @@ def _declare(lib: ctypes.CDLL) -> None:
         [c_vp] * 10 + [c_sz] + [c_int] * 7 + [c_int, c_int, c_int, c_vp, c_vp]
     )
 
-
     lib.msda_points_forward.restype = c_int
-    lib.msda_points_forward.argtypes = [c_vp] * 4 + [c_int] * 6 + [c_vp]
+    lib.msda_points_forward.argtypes = [c_vp] * 4 + [c_int] * 7 + [c_vp]
     lib.msda_points_backward.restype = c_int
-    lib.msda_points_backward.argtypes = [c_vp] * 4 + [c_int] * 6 + [c_vp]
+    lib.msda_points_backward.argtypes = [c_vp] * 4 + [c_int] * 7 + [c_vp]
     lib.msda_point_sample_forward.restype = c_int
     lib.msda_point_sample_forward.argtypes = [c_vp] * 3 + [c_int] * 8 + [c_vp]
     lib.msda_point_sample_backward.restype = c_int

@@ -12,7 +12,7 @@ namespace {
 
 using namespace msda;
 
-constexpr int kAbiVersion = 4;
+constexpr int kAbiVersion = 5;
 
 inline size_t elem_size(int dtype) {
   switch (dtype) {
@@ -244,9 +244,9 @@ size_t msda_backward_workspace_bytes(int N, int S, int M, int D, int Lq, int L, 
   if (check_common(N, S, M, D, Lq, L, P, dtype_val, dtype_loc) != MSDA_OK) return 0;
   if (flags & MSDA_FLAG_DETERMINISTIC) return 0;
   if (!(flags & MSDA_FLAG_GENERIC)) {
-    const int64_t t = tuned_backward_workspace_bytes(N, S, M, D, Lq, L, P, dtype_val, dtype_loc,
-                                                     !(flags & MSDA_FLAG_ATOMIC_SCATTER),
-                                                     shapes_host);
+    const int64_t t = tuned_backward_workspace_bytes(
+        N, S, M, D, Lq, L, P, dtype_val, dtype_loc, !(flags & MSDA_FLAG_ATOMIC_SCATTER),
+        (flags & MSDA_FLAG_TILE_1D) ? nullptr : shapes_host);
     if (t >= 0) return static_cast<size_t>(t);
   }
   if (needs_f32_image(dtype_val)) return static_cast<size_t>(N) * S * M * D * sizeof(float);
@@ -283,8 +283,8 @@ int msda_backward(const void* grad_out, const void* value, const int64_t* shapes
     const int t = tuned_backward(grad_out, value, shapes_dev, lsi_dev, loc, attn, grad_value,
                                  grad_loc, grad_attn, workspace, N, S, M, D, Lq, L, P, dtype_val,
                                  dtype_loc, !(flags & MSDA_FLAG_ATOMIC_SCATTER),
-                                 (flags & MSDA_FLAG_VALUE_HEAD_MAJOR) != 0, packed, shapes_host,
-                                 stream);
+                                 (flags & MSDA_FLAG_VALUE_HEAD_MAJOR) != 0, packed,
+                                 (flags & MSDA_FLAG_TILE_1D) ? nullptr : shapes_host, stream);
     if (t != kNotTuned) return t;
   }
   if ((flags & MSDA_FLAG_VALUE_HEAD_MAJOR) || packed) return MSDA_ELAYOUT;
@@ -303,14 +303,24 @@ int msda_backward(const void* grad_out, const void* value, const int64_t* shapes
   return MSDA_EDTYPE;
 }
 
+namespace {
+// raw / packed element types of the point epilogue: equal, or a 16-bit raw with fp32 packed
+inline int check_point_dtypes(int dtype_raw, int dtype_packed) {
+  const bool ok_raw = dtype_raw == MSDA_F32 || dtype_raw == MSDA_BF16 || dtype_raw == MSDA_F16;
+  if (!ok_raw) return MSDA_EDTYPE;
+  if (dtype_packed == dtype_raw) return MSDA_OK;
+  return dtype_packed == MSDA_F32 ? MSDA_OK : MSDA_EDTYPE;
+}
+}  // namespace
+
 int msda_points_forward(const void* raw, const void* ref_points, const int64_t* shapes_dev,
-                        void* packed, int N, int Lq, int M, int L, int P, int dtype,
-                        void* hip_stream) {
+                        void* packed, int N, int Lq, int M, int L, int P, int dtype_raw,
+                        int dtype_packed, void* hip_stream) {
   if (!raw || !ref_points || !shapes_dev || !packed) return MSDA_ENULL;
   if (N < 1 || Lq < 1 || M < 1) return MSDA_ESHAPE;
   if (L < 1 || P < 1 || L > 16 || L * P > 128) return MSDA_ELEVELS;
-  if (dtype != MSDA_F32 && dtype != MSDA_BF16 && dtype != MSDA_F16) return MSDA_EDTYPE;
-  if (!aligned(raw, 16) || !aligned(packed, 16) || !aligned(ref_points, elem_size(dtype)) ||
+  if (check_point_dtypes(dtype_raw, dtype_packed) != MSDA_OK) return MSDA_EDTYPE;
+  if (!aligned(raw, 16) || !aligned(packed, 16) || !aligned(ref_points, elem_size(dtype_packed)) ||
       !aligned(shapes_dev, 8))
     return MSDA_EALIGN;
   const int64_t rows = static_cast<int64_t>(N) * Lq * M;
@@ -319,27 +329,31 @@ int msda_points_forward(const void* raw, const void* ref_points, const int64_t* 
   if (blocks > INT32_MAX) return MSDA_ESHAPE;
   const size_t lds = points_lds_bytes(L, P, rpb, false);
   hipStream_t stream = static_cast<hipStream_t>(hip_stream);
-#define MSDA_PF(LT)                                                                           \
-  hipLaunchKernelGGL((points_forward_kernel<LT>), dim3(static_cast<unsigned>(blocks)),        \
-                     dim3(256), lds, stream, static_cast<const LT*>(raw),                     \
+#define MSDA_PF(RT, LT)                                                                       \
+  hipLaunchKernelGGL((points_forward_kernel<RT, LT>), dim3(static_cast<unsigned>(blocks)),    \
+                     dim3(256), lds, stream, static_cast<const RT*>(raw),                     \
                      static_cast<const LT*>(ref_points), shapes_dev, static_cast<LT*>(packed), \
                      rows, M, L, P, rpb)
-  switch (dtype) {
-    case MSDA_F32: MSDA_PF(float); break;
-    case MSDA_BF16: MSDA_PF(bf16_t); break;
-    default: MSDA_PF(f16_t); break;
+  switch (dtype_raw) {
+    case MSDA_F32: MSDA_PF(float, float); break;
+    case MSDA_BF16:
+      if (dtype_packed == MSDA_F32) MSDA_PF(bf16_t, float); else MSDA_PF(bf16_t, bf16_t);
+      break;
+    default:
+      if (dtype_packed == MSDA_F32) MSDA_PF(f16_t, float); else MSDA_PF(f16_t, f16_t);
+      break;
   }
 #undef MSDA_PF
   return launch_status();
 }
 
 int msda_points_backward(const void* grad_packed, const void* packed, const int64_t* shapes_dev,
-                         void* grad_raw, int N, int Lq, int M, int L, int P, int dtype,
-                         void* hip_stream) {
+                         void* grad_raw, int N, int Lq, int M, int L, int P, int dtype_raw,
+                         int dtype_packed, void* hip_stream) {
   if (!grad_packed || !packed || !shapes_dev || !grad_raw) return MSDA_ENULL;
   if (N < 1 || Lq < 1 || M < 1) return MSDA_ESHAPE;
   if (L < 1 || P < 1 || L > 16 || L * P > 128) return MSDA_ELEVELS;
-  if (dtype != MSDA_F32 && dtype != MSDA_BF16 && dtype != MSDA_F16) return MSDA_EDTYPE;
+  if (check_point_dtypes(dtype_raw, dtype_packed) != MSDA_OK) return MSDA_EDTYPE;
   if (!aligned(grad_packed, 16) || !aligned(packed, 16) || !aligned(grad_raw, 16) ||
       !aligned(shapes_dev, 8))
     return MSDA_EALIGN;
@@ -349,15 +363,19 @@ int msda_points_backward(const void* grad_packed, const void* packed, const int6
   if (blocks > INT32_MAX) return MSDA_ESHAPE;
   const size_t lds = points_lds_bytes(L, P, rpb, true);
   hipStream_t stream = static_cast<hipStream_t>(hip_stream);
-#define MSDA_PB(LT)                                                                            \
-  hipLaunchKernelGGL((points_backward_kernel<LT>), dim3(static_cast<unsigned>(blocks)),        \
+#define MSDA_PB(RT, LT)                                                                        \
+  hipLaunchKernelGGL((points_backward_kernel<RT, LT>), dim3(static_cast<unsigned>(blocks)),    \
                      dim3(256), lds, stream, static_cast<const LT*>(grad_packed),              \
-                     static_cast<const LT*>(packed), shapes_dev, static_cast<LT*>(grad_raw),   \
+                     static_cast<const LT*>(packed), shapes_dev, static_cast<RT*>(grad_raw),   \
                      rows, L, P, rpb)
-  switch (dtype) {
-    case MSDA_F32: MSDA_PB(float); break;
-    case MSDA_BF16: MSDA_PB(bf16_t); break;
-    default: MSDA_PB(f16_t); break;
+  switch (dtype_raw) {
+    case MSDA_F32: MSDA_PB(float, float); break;
+    case MSDA_BF16:
+      if (dtype_packed == MSDA_F32) MSDA_PB(bf16_t, float); else MSDA_PB(bf16_t, bf16_t);
+      break;
+    default:
+      if (dtype_packed == MSDA_F32) MSDA_PB(f16_t, float); else MSDA_PB(f16_t, f16_t);
+      break;
   }
 #undef MSDA_PB
   return launch_status();

@@ -83,10 +83,12 @@ __device__ __forceinline__ void lds_to_rows(const float* rows, int64_t first_row
   }
 }
 
-// forward: raw -> packed
-template <typename LT>
+// forward: raw -> packed.  RT: element type of the projection output (and of its gradient), LT:
+// element type of the reference points and of the packed tensor (fp32 next to a 16-bit RT keeps
+// the sampling locations at full resolution: a bf16 location near 1.0 moves in steps of 1/256).
+template <typename RT, typename LT>
 __global__ __launch_bounds__(256) void points_forward_kernel(
-    const LT* __restrict__ raw, const LT* __restrict__ ref, const int64_t* __restrict__ shapes,
+    const RT* __restrict__ raw, const LT* __restrict__ ref, const int64_t* __restrict__ shapes,
     LT* __restrict__ packed, int64_t n_rows_total, int M, int L, int P, int rpb) {
   extern __shared__ float rows[];
   __shared__ float inv_wh[2 * 16];
@@ -132,10 +134,10 @@ __global__ __launch_bounds__(256) void points_forward_kernel(
 
 // backward: (grad_packed, packed) -> grad_raw
 //   d dx = d x / W_l, d dy = d y / H_l;  d logit_i = w_i * (g_i - sum_k w_k g_k)
-template <typename LT>
+template <typename RT, typename LT>
 __global__ __launch_bounds__(256) void points_backward_kernel(
     const LT* __restrict__ grad_packed, const LT* __restrict__ packed,
-    const int64_t* __restrict__ shapes, LT* __restrict__ grad_raw, int64_t n_rows_total, int L,
+    const int64_t* __restrict__ shapes, RT* __restrict__ grad_raw, int64_t n_rows_total, int L,
     int P, int rpb) {
   extern __shared__ float rows[];  // gradient rows, then the weight rows
   __shared__ float inv_wh[2 * 16];

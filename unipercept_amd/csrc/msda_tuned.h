@@ -22,7 +22,6 @@
 #pragma once
 
 
-#include <cstdlib>
 #include <initializer_list>
 #include <type_traits>
 
@@ -148,10 +147,10 @@ constexpr int kTileShift = 6;       // positions per destination tile: 64, one p
 constexpr int kTileWidthShift = 3;  // 2-D tiles are 8 x 8 patches
 
 // Destination tiles of the binned grad_value scatter.  tile2d = 0: a tile is TS consecutive
-// positions of the flattened (level-concatenated) sequence.  tile2d = 1: a tile is a
-// (TS/16) x 16 pixel patch of one level — a bilinear footprint then straddles two tiles only
-// near patch edges (1.13 records per point instead of 1.58 on the Cityscapes pyramid); the tile
-// count needs the level shapes on the host.
+// positions of the flattened (level-concatenated) sequence.  tile2d = 1: a tile is an 8 x 8 pixel
+// patch of one level — a bilinear footprint then straddles two tiles only near patch edges
+// (1.27 records per point instead of about 2 on the Cityscapes pyramid); the tile count needs
+// the level shapes on the host.
 struct BinPlan {
   int ts_shift;     // log2 of the tile size in positions
   int n_tiles;      // tiles per (batch, head) slab
@@ -1025,7 +1024,7 @@ inline bool make_bin_plan(int N, int S, int M, int D, int Lq, int L, int P,
   };
   int64_t n_tiles = (static_cast<int64_t>(S) + TS - 1) / TS;
   int tile2d = 0;
-  if (levels_host != nullptr && getenv("MSDA_TILE_1D") == nullptr) {
+  if (levels_host != nullptr) {
     const int tw = 1 << tw_shift, th = TS >> tw_shift;
     int64_t total = 0, nt = 0;
     bool ok = true;

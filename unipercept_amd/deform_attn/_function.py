@@ -15,25 +15,57 @@ from torch.autograd.function import once_differentiable
 from .. import _lib
 from . import _ops
 
-# fp64 exists for gradcheck; below this much work the reproducible (atomic-free) grad_value path
-# is used for it, so that two backward passes agree bitwise (gradcheck's default nondet_tol is 0)
-_DET_FP64_WORK_LIMIT = 1 << 31
+# The reproducible grad_value path (MSDA_FLAG_DETERMINISTIC) walks all Lq*P points of a level
+# for every grad_value element: fine for gradcheck-sized problems, effectively a hang at
+# benchmark sizes.  fp64 exists for gradcheck; below this much work it takes that path, so that
+# two backward passes agree bitwise (gradcheck's default nondet_tol is 0).  The same limit bounds
+# what `torch.use_deterministic_algorithms(True)` may route there.
+_DET_WORK_LIMIT = 1 << 31
 
 
 def backward_flags(value: torch.Tensor, sampling_locations: torch.Tensor) -> int:
+    """Flags of the backward launch.  Evaluated ONCE, in the forward: the layout choices made
+    there (per-head value copy, packed points) must match the kernels the backward will run."""
     flags = 0
     if os.environ.get("MSDA_FORCE_GENERIC") == "1":
         flags |= _lib.FLAG_GENERIC
     if os.environ.get("MSDA_ATOMIC_SCATTER") == "1":
         flags |= _lib.FLAG_ATOMIC_SCATTER
+    if os.environ.get("MSDA_TILE_1D") == "1":
+        flags |= _lib.FLAG_TILE_1D
     det = os.environ.get("MSDA_DETERMINISTIC")
-    if det == "1" or (det != "0" and torch.are_deterministic_algorithms_enabled()):
+    lq, p = sampling_locations.shape[1], sampling_locations.shape[4]
+    small = value.numel() * lq * p <= _DET_WORK_LIMIT
+    if det == "1":
         flags |= _lib.FLAG_DETERMINISTIC
-    elif det != "0" and value.dtype == torch.float64:
-        lq, p = sampling_locations.shape[1], sampling_locations.shape[4]
-        if value.numel() * lq * p <= _DET_FP64_WORK_LIMIT:
+    elif det != "0" and torch.are_deterministic_algorithms_enabled():
+        if small:
             flags |= _lib.FLAG_DETERMINISTIC
+        else:
+            # the binned scatter uses no float atomics, but the order in which a position's
+            # contributions are added is not fixed from launch to launch: say so the way
+            # PyTorch's own non-deterministic ops do (raises unless warn_only)
+            _alert_not_deterministic(
+                "ms_deform_attn backward at this size (grad_value summation order; set "
+                "MSDA_DETERMINISTIC=1 to force the slow reproducible path)"
+            )
+    elif det != "0" and value.dtype == torch.float64 and small:
+        flags |= _lib.FLAG_DETERMINISTIC
     return flags
+
+
+def _alert_not_deterministic(what: str) -> None:
+    """Raises (or warns, under warn_only) like a PyTorch op without a deterministic kernel."""
+    msg = (
+        f"{what} does not have a deterministic implementation, but you set "
+        "'torch.use_deterministic_algorithms(True)'."
+    )
+    if torch.is_deterministic_algorithms_warn_only_enabled():
+        import warnings
+
+        warnings.warn(msg + " (warn_only=True: continuing with the non-reproducible path)")
+    else:
+        raise RuntimeError(msg)
 
 
 def forward_flags() -> int:
@@ -72,6 +104,8 @@ class MultiScaleDeformAttnFunction(torch.autograd.Function):
             # one re-layout serves both passes: the copy is what gets saved for the backward
             value = _ops.ms_deform_attn_value_head_major(value)
             fflags |= _lib.FLAG_VALUE_HEAD_MAJOR
+            bflags |= _lib.FLAG_VALUE_HEAD_MAJOR
+        ctx.bwd_flags = bflags
         out = _ops.ms_deform_attn_fwd(
             value, spatial_shapes, level_start_index, sampling_locations, attention_weights, fflags
         )
@@ -86,12 +120,9 @@ class MultiScaleDeformAttnFunction(torch.autograd.Function):
         value, spatial_shapes, level_start_index, sampling_locations, attention_weights = (
             ctx.saved_tensors
         )
-        flags = backward_flags(value, sampling_locations)
-        if ctx.head_major:
-            flags |= _lib.FLAG_VALUE_HEAD_MAJOR
         grad_value, grad_loc, grad_attn = _ops.ms_deform_attn_bwd(
             grad_output, value, spatial_shapes, level_start_index, sampling_locations,
-            attention_weights, flags,
+            attention_weights, ctx.bwd_flags,
         )
         return grad_value, None, None, grad_loc, grad_attn, None
 
@@ -142,6 +173,8 @@ class MultiScaleFlashAttnFunction(torch.autograd.Function):
         if ctx.head_major:
             value = _ops.ms_deform_attn_value_head_major(value)
             fflags |= _lib.FLAG_VALUE_HEAD_MAJOR
+            bflags |= _lib.FLAG_VALUE_HEAD_MAJOR
+        ctx.bwd_flags = bflags
         if ctx.direct:
             out = _ops.ms_flash_attn_fwd(value, spatial_shapes, level_start_index, packed, fflags)
             ctx.save_for_backward(value, spatial_shapes, level_start_index, packed)
@@ -156,22 +189,13 @@ class MultiScaleFlashAttnFunction(torch.autograd.Function):
     def backward(ctx, grad_output: torch.Tensor):
         if ctx.direct:
             value, spatial_shapes, level_start_index, packed = ctx.saved_tensors
-            levels = int(spatial_shapes.shape[0])
-            lp = packed.shape[-1] // 3
-            loc_view = packed[..., : 2 * lp].unflatten(-1, (levels, lp // levels, 2))
-            flags = backward_flags(value, loc_view)
-            if ctx.head_major:
-                flags |= _lib.FLAG_VALUE_HEAD_MAJOR
             grad_value, grad_packed = _ops.ms_flash_attn_bwd(
-                grad_output, value, spatial_shapes, level_start_index, packed, flags
+                grad_output, value, spatial_shapes, level_start_index, packed, ctx.bwd_flags
             )
             return grad_value, None, None, grad_packed, None
         value, spatial_shapes, level_start_index, loc, attn = ctx.saved_tensors
-        flags = backward_flags(value, loc)
-        if ctx.head_major:
-            flags |= _lib.FLAG_VALUE_HEAD_MAJOR
         grad_value, grad_loc, grad_attn = _ops.ms_deform_attn_bwd(
-            grad_output, value, spatial_shapes, level_start_index, loc, attn, flags
+            grad_output, value, spatial_shapes, level_start_index, loc, attn, ctx.bwd_flags
         )
         grad_packed = torch.cat((grad_loc.flatten(-3), grad_attn.flatten(-2)), dim=-1)
         return grad_value, None, None, grad_packed, None
@@ -187,6 +211,7 @@ class SamplingPointsFunction(torch.autograd.Function):
     def forward(ctx, raw, reference_points, spatial_shapes):
         packed = _ops.ms_deform_points_fwd(raw, reference_points, spatial_shapes)
         ctx.save_for_backward(packed, spatial_shapes)
+        ctx.raw_dtype = raw.dtype
         ctx.ref_needs_grad = reference_points.requires_grad
         ctx.ref_dtype = reference_points.dtype
         return packed
@@ -195,7 +220,7 @@ class SamplingPointsFunction(torch.autograd.Function):
     @once_differentiable
     def backward(ctx, grad_packed):
         packed, spatial_shapes = ctx.saved_tensors
-        grad_raw = _ops.ms_deform_points_bwd(grad_packed, packed, spatial_shapes)
+        grad_raw = _ops.ms_deform_points_bwd(grad_packed, packed, spatial_shapes, ctx.raw_dtype)
         grad_ref = None
         if ctx.ref_needs_grad:
             n, lq, m, width = packed.shape

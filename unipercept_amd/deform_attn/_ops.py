@@ -360,11 +360,18 @@ def _points_dims(raw: torch.Tensor, shapes: torch.Tensor):
     return n, lq, m, levels, width // (3 * levels)
 
 
+def _packed_point_dtype(raw_dtype: torch.dtype, reference_points: torch.Tensor) -> torch.dtype:
+    """Element type of the packed locations+weights: fp32 whenever the reference points are fp32
+    (a 16-bit projection output must not quantise the sampling locations), else raw's."""
+    return torch.float32 if reference_points.dtype == torch.float32 else raw_dtype
+
+
 @torch.library.custom_op("unipercept::ms_deform_points_fwd", mutates_args=())
 def ms_deform_points_fwd(
     raw: torch.Tensor, reference_points: torch.Tensor, spatial_shapes: torch.Tensor
 ) -> torch.Tensor:
-    """Raw (dx, dy) offsets + attention logits -> packed locations + softmax weights, one pass."""
+    """Raw (dx, dy) offsets + attention logits -> packed locations + softmax weights, one pass.
+    The result is fp32 when the reference points are (also next to a 16-bit `raw`)."""
     lib = _lib.load()
     n, lq, m, l, p = _points_dims(raw, spatial_shapes)
     if raw.dtype not in _POINT_DTYPES:
@@ -375,14 +382,15 @@ def ms_deform_points_fwd(
         raise ValueError(
             f"reference_points must be {(n, lq, l, 2)}, got {tuple(reference_points.shape)}"
         )
+    pdt = _packed_point_dtype(raw.dtype, reference_points)
     raw = raw.contiguous()
-    ref = reference_points.to(device=raw.device, dtype=raw.dtype).contiguous()
+    ref = reference_points.to(device=raw.device, dtype=pdt).contiguous()
     shapes = spatial_shapes.to(device=raw.device, dtype=torch.int64).contiguous()
-    packed = torch.empty_like(raw)
+    packed = torch.empty(raw.shape, dtype=pdt, device=raw.device)
     with torch.cuda.device_of(raw):
         rc = lib.msda_points_forward(
             raw.data_ptr(), ref.data_ptr(), shapes.data_ptr(), packed.data_ptr(), n, lq, m, l, p,
-            _DTYPE_CODE[raw.dtype], _stream_ptr(raw.device),
+            _DTYPE_CODE[raw.dtype], _DTYPE_CODE[pdt], _stream_ptr(raw.device),
         )
     _lib.check(rc, "msda_points_forward")
     return packed
@@ -390,36 +398,41 @@ def ms_deform_points_fwd(
 
 @ms_deform_points_fwd.register_fake
 def _(raw, reference_points, spatial_shapes):
-    return torch.empty_like(raw, memory_format=torch.contiguous_format)
+    return torch.empty(
+        raw.shape, dtype=_packed_point_dtype(raw.dtype, reference_points), device=raw.device
+    )
 
 
 @torch.library.custom_op("unipercept::ms_deform_points_bwd", mutates_args=())
 def ms_deform_points_bwd(
-    grad_packed: torch.Tensor, packed: torch.Tensor, spatial_shapes: torch.Tensor
+    grad_packed: torch.Tensor, packed: torch.Tensor, spatial_shapes: torch.Tensor, raw_dtype: torch.dtype
 ) -> torch.Tensor:
-    """Gradient of ms_deform_points_fwd with respect to its raw input."""
+    """Gradient of ms_deform_points_fwd with respect to its raw input (in `raw_dtype`)."""
     lib = _lib.load()
     n, lq, m, l, p = _points_dims(packed, spatial_shapes)
     if packed.device.type != "cuda" or grad_packed.device != packed.device:
         raise RuntimeError("ms_deform_points runs only on a ROCm GPU")
+    if raw_dtype not in _POINT_DTYPES or packed.dtype not in (raw_dtype, torch.float32):
+        raise TypeError(f"unsupported dtypes: raw {raw_dtype}, packed {packed.dtype}")
     packed = packed.contiguous()
     grad_packed = grad_packed.to(packed.dtype).contiguous()
     if grad_packed.shape != packed.shape:
         raise ValueError(f"grad must be {tuple(packed.shape)}, got {tuple(grad_packed.shape)}")
     shapes = spatial_shapes.to(device=packed.device, dtype=torch.int64).contiguous()
-    grad_raw = torch.empty_like(packed)
+    grad_raw = torch.empty(packed.shape, dtype=raw_dtype, device=packed.device)
     with torch.cuda.device_of(packed):
         rc = lib.msda_points_backward(
             grad_packed.data_ptr(), packed.data_ptr(), shapes.data_ptr(), grad_raw.data_ptr(),
-            n, lq, m, l, p, _DTYPE_CODE[packed.dtype], _stream_ptr(packed.device),
+            n, lq, m, l, p, _DTYPE_CODE[raw_dtype], _DTYPE_CODE[packed.dtype],
+            _stream_ptr(packed.device),
         )
     _lib.check(rc, "msda_points_backward")
     return grad_raw
 
 
 @ms_deform_points_bwd.register_fake
-def _(grad_packed, packed, spatial_shapes):
-    return torch.empty_like(packed, memory_format=torch.contiguous_format)
+def _(grad_packed, packed, spatial_shapes, raw_dtype):
+    return torch.empty(packed.shape, dtype=raw_dtype, device=packed.device)
 
 
 @torch.library.custom_op("unipercept::ms_deform_attn_value_head_major", mutates_args=())

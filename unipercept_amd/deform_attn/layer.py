@@ -137,7 +137,8 @@ class MSDeformAttn(nn.Module):
             return False
         n, lq, _ = query.shape
         width = 3 * self.n_levels * self.n_points
-        probe = query.new_empty((n, lq, self.n_heads, width), device="meta")
+        # the packed locations+weights are fp32 (see forward), whatever the activations' type
+        probe = torch.empty((n, lq, self.n_heads, width), dtype=torch.float32, device="meta")
         return _ops.packed_points_supported(value, probe, self.n_levels)
 
     def forward(
@@ -154,7 +155,10 @@ class MSDeformAttn(nn.Module):
             n, lq, _ = query.shape
             weight, bias = self.fused_projection()
             raw = torch.nn.functional.linear(query, weight, bias).view(n, lq, self.n_heads, -1)
-            packed = SamplingPointsFunction.apply(raw, reference_points, input_spatial_shapes)
+            # fp32 reference points make the packed locations and weights fp32 even when the
+            # projection ran in 16 bits (autocast, .bfloat16()): a bf16 location near 1.0 has a
+            # resolution of 1/256, a whole pixel on a 256-wide level
+            packed = SamplingPointsFunction.apply(raw, reference_points.float(), input_spatial_shapes)
             out = MultiScaleFlashAttnFunction.apply(
                 value, input_spatial_shapes, input_level_start_index, packed, self.im2col_step
             )

@@ -46,24 +46,36 @@ def _check(input: torch.Tensor, coords: torch.Tensor) -> None:
         raise TypeError(
             f"input and point_coords must have the same dtype, got {input.dtype} and {coords.dtype}"
         )
-    if input.device.type != "cuda" or coords.device != input.device:
+    if input.shape[2] == 0 or input.shape[3] == 0:
+        # grid_sample's own condition: only the spatial dimensions must be non-empty
+        raise ValueError(f"input must have non-empty spatial dimensions, got {tuple(input.shape)}")
+    if coords.device != input.device:
+        raise RuntimeError(f"input and point_coords are on {input.device} and {coords.device}")
+    if input.device.type != "cuda" and not _is_empty(input, coords):  # nothing to launch when empty
         raise RuntimeError(
             "pointrend.sample runs only on a ROCm GPU (HIP kernels); got tensors on "
-            f"{input.device} and {coords.device}"
+            f"{input.device}"
         )
-    if 0 in input.shape or coords.shape[1] == 0:
-        raise ValueError("empty input or empty point set")
+
+
+def _is_empty(input: torch.Tensor, coords: torch.Tensor) -> bool:
+    """No samples, channels or points: grid_sample returns an empty (N, C, P) tensor then (a
+    point-based mask loss on a batch without instances), and so does this drop-in, without a
+    launch."""
+    return input.shape[0] == 0 or input.shape[1] == 0 or coords.shape[1] == 0
 
 
 @torch.library.custom_op("unipercept::point_sample_fwd", mutates_args=())
 def point_sample_fwd(input: torch.Tensor, point_coords: torch.Tensor, mode: int,
                      align_corners: bool) -> torch.Tensor:
     _check(input, point_coords)
+    n, c, h, w = input.shape
+    p = point_coords.shape[1]
+    if _is_empty(input, point_coords):
+        return input.new_empty((n, c, p))
     lib = _lib.load()
     input = input.contiguous()
     coords = point_coords.contiguous()
-    n, c, h, w = input.shape
-    p = coords.shape[1]
     out = torch.empty((n, c, p), dtype=input.dtype, device=input.device)
     with torch.cuda.device_of(input):
         rc = lib.msda_point_sample_forward(
@@ -84,6 +96,8 @@ def _(input, point_coords, mode, align_corners):
 def point_sample_bwd(grad_out: torch.Tensor, input: torch.Tensor, point_coords: torch.Tensor,
                      mode: int, align_corners: bool) -> tuple[torch.Tensor, torch.Tensor]:
     _check(input, point_coords)
+    if _is_empty(input, point_coords):
+        return torch.zeros_like(input), torch.zeros_like(point_coords)
     lib = _lib.load()
     dtype = input.dtype
     # the kernels accumulate in the tensors' own type: 16-bit inputs go through fp32
