@@ -6,7 +6,8 @@
  * The library never allocates, frees or retains pointers, never synchronises the device, and
  * launches asynchronously on the HIP stream it is given (NULL = the default stream).  There is
  * no global mutable state: the entry points may be called concurrently from several host
- * threads (autograd runs the backward on its own engine thread).
+ * threads (autograd runs the backward on its own engine thread).  The one exception is
+ * msda_backward_noalloc, whose scratch is a static array inside the library (see there).
  *
  * Tensor conventions (contiguous, row-major):
  *   value   (N, S, M, D)         S = sum_l H_l * W_l
@@ -48,6 +49,7 @@ enum {
   MSDA_ESTEP = -6,      /* im2col_step < 1 or N % min(N, im2col_step) != 0 */
   MSDA_ELEVELS = -7,    /* more levels or points than the library supports (L <= 16, L*P <= 128) */
   MSDA_ELAYOUT = -8,    /* MSDA_FLAG_VALUE_HEAD_MAJOR on a shape/path that only takes (N,S,M,D) */
+  MSDA_ENOALLOC = -9,   /* msda_backward_noalloc: scratch need beyond the static array's 128 MiB */
 };
 
 /* flags for msda_backward */
@@ -166,6 +168,33 @@ int msda_backward(const void* grad_out, const void* value, const int64_t* shapes
                   void* grad_loc, void* grad_attn, void* workspace, size_t workspace_bytes, int N,
                   int S, int M, int D, int Lq, int L, int P, int dtype_val, int dtype_loc,
                   int flags, const int64_t* shapes_host, void* hip_stream);
+
+/*
+ * msda_backward for callers that cannot allocate device memory: code under HIP graph capture,
+ * tight serving / fine-tuning loops and harnesses that forbid hipMalloc.  It has no counterpart
+ * in the reference.  Same arguments and results as msda_backward without the workspace pair: the
+ * scratch (directory, scatter records, per-head grad_out copy, or the fp32 accumulation image
+ * of the atomic paths) lives in a static 128 MiB device array inside the library, one copy per
+ * GPU the library runs on, held until the process ends.  The call itself allocates and frees
+ * nothing (no hipMalloc / hipFree, no allocating library routine).
+ *
+ * Limit: msda_backward_workspace_bytes(...) for the problem must be <= 128 MiB (134 217 728
+ * bytes), else MSDA_ENOALLOC is returned and nothing is launched; the backward of the
+ * CPU-reference configuration (512 x 1024 input: S = Lq = 10752, 8 heads x 32, 3 levels x 4
+ * points, batch 1, fp32) needs 78 MiB.  The first call on a device looks the array's address up
+ * (hipGetSymbolAddress): make that call outside graph capture.
+ *
+ * Every call on one GPU uses that GPU's one array: calls that overlap in time on the same GPU
+ * (two streams, two host threads) race on it and give undefined gradients; calls on one stream,
+ * or on different GPUs, are safe.  The array keeps the last call's contents between calls; the
+ * kernels never read a scratch word they have not written in the same call (the atomic paths
+ * clear their accumulation image first).
+ */
+int msda_backward_noalloc(const void* grad_out, const void* value, const int64_t* shapes_dev,
+                          const int64_t* lsi_dev, const void* loc, const void* attn,
+                          void* grad_value, void* grad_loc, void* grad_attn, int N, int S, int M,
+                          int D, int Lq, int L, int P, int dtype_val, int dtype_loc, int flags,
+                          const int64_t* shapes_host, void* hip_stream);
 
 /*
  * Sampling-point epilogue of the layer that calls the op.  `raw` (N, Lq, M, 3*L*P) is the output

@@ -172,6 +172,19 @@ def test_packed_points_flag_arguments():
     assert ok(0, 640, 2, 32, 5, 2, 2, _lib.F32, _lib.F32) == 0
 
 
+def test_no_alloc_backward_limit_is_checked_before_any_device_call():
+    """msda_backward_noalloc refuses a problem whose scratch exceeds the static 128 MiB array
+    (no GPU needed: the size check comes first), and validates like msda_backward otherwise."""
+    lib = _lib.load()
+    args = [FAKE] * 9
+    headline = (8, 43008, 8, 32, 43008, 3, 4)
+    assert lib.msda_backward_workspace_bytes(*headline, 0, 0, 0, None) > 128 << 20
+    assert lib.msda_backward_noalloc(*args, *headline, 0, 0, 0, None, None) == -9
+    assert b"128 MiB" in lib.msda_error_string(-9)
+    cpuref = (1, 10752, 8, 32, 10752, 3, 4)
+    assert lib.msda_backward_workspace_bytes(*cpuref, 0, 0, 0, None) <= 128 << 20
+
+
 def test_points_epilogue_argument_errors():
     lib = _lib.load()
 

@@ -10,7 +10,7 @@ from pathlib import Path
 _PKG = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ.get("MSDA_LIBRARY", _PKG / "libmsda.so"))
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 # dtype codes of include/msda.h
 F32, F64, BF16, F16 = 0, 1, 2, 3
@@ -33,6 +33,7 @@ EXPORTS = (
     "msda_value_relayout",
     "msda_backward_workspace_bytes",
     "msda_backward",
+    "msda_backward_noalloc",
     "msda_points_forward",
     "msda_points_backward",
     "msda_point_sample_forward",
@@ -69,6 +70,10 @@ def _declare(lib: ctypes.CDLL) -> None:
     lib.msda_backward.restype = c_int
     lib.msda_backward.argtypes = (
         [c_vp] * 10 + [c_sz] + [c_int] * 7 + [c_int, c_int, c_int, c_vp, c_vp]
+    )
+    lib.msda_backward_noalloc.restype = c_int
+    lib.msda_backward_noalloc.argtypes = (
+        [c_vp] * 9 + [c_int] * 7 + [c_int, c_int, c_int, c_vp, c_vp]
     )
 
     lib.msda_points_forward.restype = c_int

@@ -3,6 +3,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <mutex>
+
 #include "msda_generic.h"
 #include "msda_points.h"
 #include "msda_sample.h"
@@ -12,7 +14,7 @@ namespace {
 
 using namespace msda;
 
-constexpr int kAbiVersion = 5;
+constexpr int kAbiVersion = 6;
 
 inline size_t elem_size(int dtype) {
   switch (dtype) {
@@ -136,6 +138,42 @@ int bwd_generic(const void* grad_out, const void* value, const int64_t* shapes, 
 
 inline bool needs_f32_image(int dtype_val) { return dtype_val == MSDA_BF16 || dtype_val == MSDA_F16; }
 
+int backward_impl(const void* grad_out, const void* value, const int64_t* shapes_dev,
+                  const int64_t* lsi_dev, const void* loc, const void* attn, void* grad_value,
+                  void* grad_loc, void* grad_attn, void* workspace, size_t workspace_bytes, int N,
+                  int S, int M, int D, int Lq, int L, int P, int dtype_val, int dtype_loc,
+                  int flags, const int64_t* shapes_host, void* hip_stream);
+
+// ---- msda_backward_noalloc: the backward's scratch as a static device array ------------------
+// 128 MiB per GPU the library runs on, held until the process ends: enough for the backward of
+// the CPU-reference configuration (512 x 1024 input, batch 1: 78 MiB) and anything smaller.
+constexpr size_t kNoAllocScratchBytes = static_cast<size_t>(128) << 20;
+__device__ __align__(256) unsigned char scratch[kNoAllocScratchBytes];
+
+// In host code `scratch` is only a handle for the symbol, not a device address.  Every GPU has
+// its own copy of the array at its own address: it is looked up once per device, with that
+// device current, and every later use goes through the pointer kept here.
+constexpr int kMaxDevices = 64;
+std::mutex scratch_mutex;
+void* scratch_ptr[kMaxDevices] = {};
+
+int noalloc_scratch(void** out) {
+  int dev = -1;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return static_cast<int>(e);
+  if (dev < 0 || dev >= kMaxDevices) return MSDA_ENOALLOC;
+  std::lock_guard<std::mutex> lock(scratch_mutex);
+  if (scratch_ptr[dev] == nullptr) {
+    void* p = nullptr;
+    e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+    if (e != hipSuccess) return static_cast<int>(e);
+    if (p == nullptr || reinterpret_cast<uintptr_t>(p) % 256 != 0) return MSDA_ENOALLOC;
+    scratch_ptr[dev] = p;
+  }
+  *out = scratch_ptr[dev];
+  return MSDA_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -154,6 +192,10 @@ const char* msda_error_string(int code) {
     case MSDA_ELEVELS: return "msda: too many levels/points (L <= 16, L*P <= 128)";
     case MSDA_ELAYOUT:
       return "msda: head-major value / packed point layout is not supported for this shape/path";
+    case MSDA_ENOALLOC:
+      return "msda: msda_backward_noalloc: the problem needs more scratch than the library's "
+             "static 128 MiB array (see msda_backward_workspace_bytes), or the device ordinal is "
+             "beyond 63";
     default:
       return code > 0 ? hipGetErrorString(static_cast<hipError_t>(code)) : "msda: unknown error";
   }
@@ -258,6 +300,38 @@ int msda_backward(const void* grad_out, const void* value, const int64_t* shapes
                   void* grad_loc, void* grad_attn, void* workspace, size_t workspace_bytes, int N,
                   int S, int M, int D, int Lq, int L, int P, int dtype_val, int dtype_loc,
                   int flags, const int64_t* shapes_host, void* hip_stream) {
+  return backward_impl(grad_out, value, shapes_dev, lsi_dev, loc, attn, grad_value, grad_loc,
+                       grad_attn, workspace, workspace_bytes, N, S, M, D, Lq, L, P, dtype_val,
+                       dtype_loc, flags, shapes_host, hip_stream);
+}
+
+int msda_backward_noalloc(const void* grad_out, const void* value, const int64_t* shapes_dev,
+                          const int64_t* lsi_dev, const void* loc, const void* attn,
+                          void* grad_value, void* grad_loc, void* grad_attn, int N, int S, int M,
+                          int D, int Lq, int L, int P, int dtype_val, int dtype_loc, int flags,
+                          const int64_t* shapes_host, void* hip_stream) {
+  // size check first: a problem beyond the static array is refused before any HIP call
+  const size_t need = msda_backward_workspace_bytes(N, S, M, D, Lq, L, P, dtype_val, dtype_loc,
+                                                    flags, shapes_host);
+  if (need > kNoAllocScratchBytes) return MSDA_ENOALLOC;
+  void* ws = nullptr;
+  if (need > 0) {
+    const int rc = noalloc_scratch(&ws);
+    if (rc != MSDA_OK) return rc;
+  }
+  return backward_impl(grad_out, value, shapes_dev, lsi_dev, loc, attn, grad_value, grad_loc,
+                       grad_attn, ws, need > 0 ? kNoAllocScratchBytes : 0, N, S, M, D, Lq, L, P,
+                       dtype_val, dtype_loc, flags, shapes_host, hip_stream);
+}
+
+}  // extern "C"
+
+namespace {
+int backward_impl(const void* grad_out, const void* value, const int64_t* shapes_dev,
+                  const int64_t* lsi_dev, const void* loc, const void* attn, void* grad_value,
+                  void* grad_loc, void* grad_attn, void* workspace, size_t workspace_bytes, int N,
+                  int S, int M, int D, int Lq, int L, int P, int dtype_val, int dtype_loc,
+                  int flags, const int64_t* shapes_host, void* hip_stream) {
   const bool packed = (flags & MSDA_FLAG_PACKED_POINTS) != 0;  // attn / grad_attn not looked at
   if (!grad_out || !value || !shapes_dev || !lsi_dev || !loc || !grad_value || !grad_loc ||
       (!packed && (!attn || !grad_attn)))
@@ -302,6 +376,9 @@ int msda_backward(const void* grad_out, const void* value, const int64_t* shapes
 #undef MSDA_BWD
   return MSDA_EDTYPE;
 }
+}  // namespace
+
+extern "C" {
 
 namespace {
 // raw / packed element types of the point epilogue: equal, or a 16-bit raw with fp32 packed
