@@ -23,7 +23,7 @@ def hip_command(out: Path) -> list[str]:
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     return [
         hipcc, "-O3", f"--offload-arch={HIP_ARCH}", "-std=c++17", "-shared", "-fPIC",
-        "-munsafe-fp-atomics", "-Wall", "-Wno-unused-function", "-Wno-pass-failed",
+        "-munsafe-fp-atomics", "-fno-slp-vectorize", "-Wall", "-Wno-unused-function", "-Wno-pass-failed",
         "-o", str(out), str(ROOT / "unipercept_amd" / "csrc" / "msda.hip"),
     ]
 

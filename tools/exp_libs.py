@@ -10,6 +10,23 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from unipercept_amd import harness, _lib
 w = harness.WORKLOADS[os.environ.get("WORKLOAD", "cityscapes_1024x2048_fp32_b8")]
 value, shapes, lsi, loc, attn, g = harness.synth_inputs(w, "cuda", seed=1, dist=os.environ.get("DIST", "R"))
+def query_order(levels, spec):
+    """QPERM=<th>x<tw>[c]: queries visited patch by patch (th x tw pixels of their own level,
+    row-major inside), patches in raster order, or column by column with the 'c' suffix."""
+    col = spec.endswith("c"); th, tw = (int(x) for x in spec.rstrip("c").split("x"))
+    out, base = [], 0
+    for h, w in levels:
+        idx = torch.arange(h * w).view(h, w)
+        ph, pw = -(-h // th), -(-w // tw)
+        tiles = [(i, j) for j in range(pw) for i in range(ph)] if col else [(i, j) for i in range(ph) for j in range(pw)]
+        for i, j in tiles:
+            out.append(idx[i * th:(i + 1) * th, j * tw:(j + 1) * tw].reshape(-1) + base)
+        base += h * w
+    return torch.cat(out)
+if os.environ.get("QPERM"):
+    perm = query_order(w.levels, os.environ["QPERM"]).cuda()
+    loc, attn, g = loc[:, perm].contiguous(), attn[:, perm].contiguous(), g[:, perm].contiguous()
+    print("query order", os.environ["QPERM"], flush=True)
 n, s, m, d = value.shape; lq, l, p = loc.shape[1], loc.shape[3], loc.shape[4]
 code = {torch.float32: 0, torch.bfloat16: 2}
 dv, dl = code[value.dtype], code[loc.dtype]

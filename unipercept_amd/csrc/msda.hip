@@ -180,6 +180,19 @@ extern "C" {
 
 int msda_version(void) { return kAbiVersion; }
 
+#if MSDA_STAMPS
+// diagnostic builds only: copies the per-workgroup phase cycle sums of kernel `which` (0 query
+// kernel, 1 tile kernel) to host memory; returns the number of workgroup rows
+int msda_debug_read_stamps(int which, unsigned long long* host, int max_groups) {
+  const int n = max_groups < msda::kStampGroups ? max_groups : msda::kStampGroups;
+  hipDeviceSynchronize();
+  const hipError_t e = hipMemcpyFromSymbol(
+      host, HIP_SYMBOL(msda::stamp_buf), static_cast<size_t>(n) * msda::kStampSlots * 8,
+      static_cast<size_t>(which) * msda::kStampGroups * msda::kStampSlots * 8, hipMemcpyDeviceToHost);
+  return e == hipSuccess ? n : -static_cast<int>(e);
+}
+#endif
+
 const char* msda_error_string(int code) {
   switch (code) {
     case MSDA_OK: return "success";

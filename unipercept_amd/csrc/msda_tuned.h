@@ -38,6 +38,43 @@ namespace msda {
 #endif
 constexpr int kAblate = MSDA_ABLATE;
 
+// Diagnostic builds only (-DMSDA_STAMPS=1): thread 0 of every workgroup of the two backward
+// kernels adds up the shader cycles it spends in each phase (s_memtime stamps behind the
+// workgroup barriers) and leaves the sums in a device buffer of the library, read back through
+// msda_debug_read_stamps().  Never defined in the shipped library.
+#ifndef MSDA_STAMPS
+#define MSDA_STAMPS 0
+#endif
+#if MSDA_STAMPS
+constexpr int kStampSlots = 16;
+constexpr int kStampGroups = 1 << 15;
+__device__ unsigned long long stamp_buf[2][kStampGroups][kStampSlots];
+__device__ __forceinline__ unsigned long long stamp_now() {
+  unsigned long long t;
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  __builtin_amdgcn_sched_barrier(0);
+  return t;
+}
+#define MSDA_STAMP_DECL unsigned long long st_prev = stamp_now(), st_acc[kStampSlots] = {}
+#define MSDA_STAMP(i)                              \
+  do {                                             \
+    const unsigned long long st_t = stamp_now();   \
+    st_acc[i] += st_t - st_prev;                   \
+    st_prev = st_t;                                \
+  } while (0)
+#define MSDA_STAMP_FLUSH(k)                                                               \
+  do {                                                                                    \
+    const unsigned wg = blockIdx.y * gridDim.x + blockIdx.x;                              \
+    if (threadIdx.x == 0 && wg < kStampGroups)                                            \
+      for (int st_i = 0; st_i < kStampSlots; ++st_i) stamp_buf[k][wg][st_i] = st_acc[st_i]; \
+  } while (0)
+#else
+#define MSDA_STAMP_DECL
+#define MSDA_STAMP(i)
+#define MSDA_STAMP_FLUSH(k)
+#endif
+
 // The query kernel leaves a per-head copy (N, M, Lq, D) of grad_out in the workspace and the
 // tile kernel gathers its rows from that copy: in the (N, Lq, M, D) tensor a head's rows are
 // M*D*e bytes apart and fall on 2 of the 16 channels of the XCD's L2.
@@ -59,6 +96,10 @@ struct Chunk<float> {
     const float4 t = *static_cast<const float4*>(p);
     v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
   }
+  __device__ __forceinline__ static void unpack(const uint4& t, float (&v)[4]) {
+    v[0] = __uint_as_float(t.x); v[1] = __uint_as_float(t.y);
+    v[2] = __uint_as_float(t.z); v[3] = __uint_as_float(t.w);
+  }
   __device__ __forceinline__ static void store(void* p, const float (&v)[4]) {
     *static_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
   }
@@ -67,14 +108,16 @@ struct Chunk<float> {
 template <>
 struct Chunk<bf16_t> {
   static constexpr int kCPL = 8;
-  __device__ __forceinline__ static void load(const void* p, float (&v)[8]) {
-    const uint4 t = *static_cast<const uint4*>(p);
+  __device__ __forceinline__ static void unpack(const uint4& t, float (&v)[8]) {
     const uint32_t w[4] = {t.x, t.y, t.z, t.w};
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       v[2 * i] = __uint_as_float(w[i] << 16);
       v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
     }
+  }
+  __device__ __forceinline__ static void load(const void* p, float (&v)[8]) {
+    unpack(*static_cast<const uint4*>(p), v);
   }
   __device__ __forceinline__ static void store(void* p, const float (&v)[8]) {
     uint32_t w[4];
@@ -91,6 +134,11 @@ struct Chunk<f16_t> {
   typedef _Float16 half8 __attribute__((ext_vector_type(8)));
   __device__ __forceinline__ static void load(const void* p, float (&v)[8]) {
     const half8 t = *static_cast<const half8*>(p);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = static_cast<float>(t[i]);
+  }
+  __device__ __forceinline__ static void unpack(const uint4& r, float (&v)[8]) {
+    const half8 t = __builtin_bit_cast(half8, r);
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] = static_cast<float>(t[i]);
   }
@@ -138,6 +186,25 @@ __host__ __device__ constexpr int group_stride_slots(int LP, int slots) { return
 #define MSDA_K3_WIDE 1
 #endif
 __host__ __device__ constexpr int query_lanes(int G) { return (MSDA_K3_WIDE && G >= 8) ? G / 2 : G; }
+
+// Query kernel of the binned backward: locations and weights read once, up front, into registers
+// (0: the count pass and every staging pass read them from memory).
+#ifndef MSDA_K3_PRE
+#define MSDA_K3_PRE 1
+#endif
+// Gather loop of the binned query kernel: 2 = two points (16 row loads) in flight per lane,
+// 1 = one point at a time.
+#ifndef MSDA_K3_DEPTH
+#define MSDA_K3_DEPTH 2
+#endif
+// records of a workgroup leave through an LDS image of its region (1) or one store each (0)
+#ifndef MSDA_K3_LDS_EMIT
+#define MSDA_K3_LDS_EMIT 1
+#endif
+// minimum waves per SIMD the query kernel's register allocation must allow
+#ifndef MSDA_K3_MINWAVES
+#define MSDA_K3_MINWAVES 1
+#endif
 
 // One scatter record (16 bytes): what the tile kernel needs to redo the footprint of a point.
 //   x = query index | level << 28, y = attention weight, z/w = normalised location (x, y) as f32
@@ -302,12 +369,72 @@ struct EmitCtx {
   uint32_t* tile_cnt;  // LDS: running rank per tile
   BinPlan plan;        // by value: a pointer to the kernel argument would force it into scratch
   const TileMap* tm;
+  uint4* lds_image;    // LDS image of the head of the region (null: records go out directly)
+  uint32_t lds_cap;    // records the image holds
 };
 
 // What a staged point holds: forward {weights, offsets}; backward with atomic scatter {weights,
 // offsets, fractions}; backward with binned scatter {offsets, fractions}.
 enum StageKind { kStageFwd = 0, kStageBwdAtomic = 1, kStageBwdBinned = 2 };
 __host__ __device__ constexpr int stage_slots(int kind) { return kind == kStageBwdAtomic ? 3 : 2; }
+
+// Appends the scatter records of one sampling point (footprint f on level l, query index q) to
+// the workgroup's record region: one record per destination tile the footprint touches.
+__device__ __forceinline__ void emit_records(const Footprint<float>& f, const LevelInfo& L_, int l,
+                                             float x, float y, float a, int q,
+                                             const EmitCtx& emit) {
+  if (f.any && a != 0.f && emit.records != nullptr) {
+    uint32_t tiles[4];
+    bool keep[4];
+    footprint_tiles(f, emit.plan, *emit.tm, L_, l, tiles, keep);
+    uint4 rec;
+    rec.x = static_cast<uint32_t>(q) | (static_cast<uint32_t>(l) << 28);
+    rec.y = __float_as_uint(a);
+    rec.z = __float_as_uint(x);
+    rec.w = __float_as_uint(y);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (keep[j]) {
+        const uint32_t at = emit.tile_off[tiles[j]] + atomicAdd(&emit.tile_cnt[tiles[j]], 1u);
+        if (at < emit.lds_cap) {
+          emit.lds_image[at] = rec;  // leaves the workgroup later, as part of one linear copy
+        } else if (at < emit.plan.region) {  // always true: a bug stays in the region
+          emit.records[at] = rec;
+        }
+      }
+    }
+  }
+}
+
+// Stages one sampling point (location (x, y), weight a, level l) at `dst` and, when EMIT, appends
+// its scatter records (query index q) to the workgroup's record region.
+template <int KIND, bool EMIT>
+__device__ __forceinline__ void stage_point(const LevelInfo& L_, int l, float x, float y, float a,
+                                            int q, uint4* dst, uint32_t rowb, uint32_t headb,
+                                            const EmitCtx& emit) {
+  constexpr int SLOTS = stage_slots(KIND);
+  const Footprint<float> f = footprint<float>(x, y, L_.H, L_.W);
+  uint4 wrec, orec;
+  wrec.x = __float_as_uint(a * f.w[0]);
+  wrec.y = __float_as_uint(a * f.w[1]);
+  wrec.z = __float_as_uint(a * f.w[2]);
+  wrec.w = __float_as_uint(a * f.w[3]);
+  orec.x = (static_cast<uint32_t>(L_.start + f.pix[0]) * rowb + headb) | (f.valid[0] ? 1u : 0u);
+  orec.y = (static_cast<uint32_t>(L_.start + f.pix[1]) * rowb + headb) | (f.valid[1] ? 1u : 0u);
+  orec.z = (static_cast<uint32_t>(L_.start + f.pix[2]) * rowb + headb) | (f.valid[2] ? 1u : 0u);
+  orec.w = (static_cast<uint32_t>(L_.start + f.pix[3]) * rowb + headb) | (f.valid[3] ? 1u : 0u);
+  if constexpr (KIND != kStageBwdBinned) dst[0] = wrec;
+  dst[KIND == kStageBwdBinned ? 0 : 1] = orec;
+  if constexpr (KIND != kStageFwd) {
+    uint4 frec;
+    frec.x = __float_as_uint(f.lx);
+    frec.y = __float_as_uint(f.ly);
+    frec.z = __float_as_uint(a * static_cast<float>(L_.W));
+    frec.w = __float_as_uint(a * static_cast<float>(L_.H));
+    dst[SLOTS - 1] = frec;
+  }
+  if constexpr (EMIT) emit_records(f, L_, l, x, y, a, q, emit);
+}
 
 // Stages the points of `nq` consecutive queries of head m (first query q_first) into LDS.
 template <typename LT, int KIND, bool EMIT>
@@ -326,50 +453,11 @@ __device__ __forceinline__ void stage_chunk(const LevelInfo* lv, const LT* __res
     small_divmod(t, nI, inv_nI, g, ii);
     const int i = i_first + ii;
     small_divmod(i, P, inv_P, l, p_unused);
-    const LevelInfo L_ = lv[l];
     const int64_t row = (static_cast<int64_t>(b) * Lq + q_first + g) * M + m;
     float x, y, a;
     load_point(loc, attn, row, i, rs, x, y, a);
-    const Footprint<float> f = footprint<float>(x, y, L_.H, L_.W);
-    uint4 wrec, orec;
-    wrec.x = __float_as_uint(a * f.w[0]);
-    wrec.y = __float_as_uint(a * f.w[1]);
-    wrec.z = __float_as_uint(a * f.w[2]);
-    wrec.w = __float_as_uint(a * f.w[3]);
-    orec.x = (static_cast<uint32_t>(L_.start + f.pix[0]) * rowb + headb) | (f.valid[0] ? 1u : 0u);
-    orec.y = (static_cast<uint32_t>(L_.start + f.pix[1]) * rowb + headb) | (f.valid[1] ? 1u : 0u);
-    orec.z = (static_cast<uint32_t>(L_.start + f.pix[2]) * rowb + headb) | (f.valid[2] ? 1u : 0u);
-    orec.w = (static_cast<uint32_t>(L_.start + f.pix[3]) * rowb + headb) | (f.valid[3] ? 1u : 0u);
-    uint4* dst = stage + g * stride + SLOTS * ii;
-    if constexpr (KIND != kStageBwdBinned) dst[0] = wrec;
-    dst[KIND == kStageBwdBinned ? 0 : 1] = orec;
-    if constexpr (KIND != kStageFwd) {
-      uint4 frec;
-      frec.x = __float_as_uint(f.lx);
-      frec.y = __float_as_uint(f.ly);
-      frec.z = __float_as_uint(a * static_cast<float>(L_.W));
-      frec.w = __float_as_uint(a * static_cast<float>(L_.H));
-      dst[SLOTS - 1] = frec;
-    }
-    if constexpr (EMIT) {
-      if (f.any && a != 0.f && emit.records != nullptr) {
-        uint32_t tiles[4];
-        bool keep[4];
-        footprint_tiles(f, emit.plan, *emit.tm, L_, l, tiles, keep);
-        uint4 rec;
-        rec.x = static_cast<uint32_t>(q_first + g) | (static_cast<uint32_t>(l) << 28);
-        rec.y = __float_as_uint(a);
-        rec.z = __float_as_uint(x);
-        rec.w = __float_as_uint(y);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          if (keep[j]) {
-            const uint32_t at = emit.tile_off[tiles[j]] + atomicAdd(&emit.tile_cnt[tiles[j]], 1u);
-            if (at < emit.plan.region) emit.records[at] = rec;  // always true: a bug stays in the region
-          }
-        }
-      }
-    }
+    stage_point<KIND, EMIT>(lv[l], l, x, y, a, q_first + g, stage + g * stride + SLOTS * ii, rowb,
+                            headb, emit);
   }
 }
 
@@ -547,8 +635,15 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t* data, int n, 
 
 // MODE 0: grad_loc / grad_attn + grad_value by global fp32 atomics into `gv_acc`
 // MODE 1: grad_loc / grad_attn + scatter records for the tile kernel
-template <typename VT, typename LT, int G, int MODE>
-__global__ __launch_bounds__(256) void bwd_query_kernel(
+// KPC > 0 (MODE 1, 4 lanes per query, 3 chunks of 64 queries per workgroup, all L*P points of a
+// query staged in one pass, L*P <= 4 * KPC): every thread reads the locations and weights of ALL
+// its points of the workgroup — KPC per chunk — at the start of the kernel with independent loads
+// and keeps them in registers.  The count pass and the three staging passes then work from
+// registers: the tensors are read once instead of twice, and the nine dependent global round
+// trips per thread of the count pass plus three per staging pass (each waits behind the gathers
+// of the other workgroups of the CU) become one.
+template <typename VT, typename LT, int G, int MODE, int KPC = 0>
+__global__ __launch_bounds__(256, MSDA_K3_MINWAVES) void bwd_query_kernel(
     const VT* __restrict__ grad_out, const VT* __restrict__ value,
     const int64_t* __restrict__ shapes, const int64_t* __restrict__ lsi,
     const LT* __restrict__ loc, const LT* __restrict__ attn, LT* __restrict__ grad_loc,
@@ -562,6 +657,9 @@ __global__ __launch_bounds__(256) void bwd_query_kernel(
   constexpr int GPB = 256 / GQ;
   constexpr int KIND = MODE == 1 ? kStageBwdBinned : kStageBwdAtomic;
   constexpr int SL = stage_slots(KIND);
+  constexpr int NCHUNK = 192 / GPB;                    // KPC > 0: chunks of GPB queries per workgroup
+  constexpr int PRE = KPC > 0 ? NCHUNK * KPC : 1;      // points a thread keeps in registers
+  static_assert(KPC == 0 || MODE == 1, "register-resident points: binned mode only");
   extern __shared__ uint4 lds[];
   __shared__ LevelInfo lv[kMaxLevelsTuned];
   __shared__ TileMap tm;
@@ -573,51 +671,108 @@ __global__ __launch_bounds__(256) void bwd_query_kernel(
   const int qblock = blockIdx.x / M;
   const int qb0 = qblock * plan.qb;
   const int qb_n = min(plan.qb, Lq - qb0);
+  MSDA_STAMP_DECL;
   if (threadIdx.x < L) lv[threadIdx.x] = load_level(shapes, lsi, threadIdx.x, S);
   __syncthreads();
   if (MODE == 1 && plan.tile2d) {
     if (threadIdx.x == 0) build_tile_map(lv, L, plan, tm);
     __syncthreads();
   }
+  MSDA_STAMP(0);  // level table + tile map
 
   const uint32_t rowb = static_cast<uint32_t>(head_major ? 1 : M) * D * sizeof(VT);
   const uint32_t headb = static_cast<uint32_t>(m) * (head_major ? S : 1) * D * sizeof(VT);
-  uint4* stage = lds;
+  // LDS: [tile counters | tile offsets] (binned mode), staged points, parked points (KPC > 0)
   const int stage_total = GPB * group_stride_slots(LPB, SL);
-  uint32_t* tile_cnt = reinterpret_cast<uint32_t*>(lds + stage_total);
+  const int tile_slots = MODE == 1 ? (2 * plan.n_tiles + 3) / 4 : 0;  // 16-byte slots
+  uint32_t* tile_cnt = reinterpret_cast<uint32_t*>(lds);
   uint32_t* tile_off = tile_cnt + plan.n_tiles;
+  uint4* stage = lds + tile_slots;
   EmitCtx emit{};
+
+  // KPC > 0: the thread's points.  Point j of a chunk is the chunk's point t = threadIdx.x +
+  // 256 * j, i.e. point `i` (level `l`) of query `q` of the chunk — the same for every chunk;
+  // px / py / pa hold location and weight of point j of chunk c at [c * KPC + j].
+  float px[PRE], py[PRE], pa[PRE];
+  const float inv_LP = 1.0f / static_cast<float>(LP), inv_P = 1.0f / static_cast<float>(P);
+  const auto point_of = [&](int j, int& q, int& i, int& l) {
+    int p_unused;
+    small_divmod(static_cast<int>(threadIdx.x) + 256 * j, LP, inv_LP, q, i);
+    small_divmod(i, P, inv_P, l, p_unused);
+  };
+  // pending chunks' points, parked in LDS while a chunk is gathered: [(c - 1) * KPC + j][x, y, a][thread]
+  float* stash = reinterpret_cast<float*>(stage + stage_total);
+  if constexpr (KPC > 0) {
+#pragma unroll
+    for (int c = 0; c < NCHUNK; ++c)
+#pragma unroll
+      for (int j = 0; j < KPC; ++j) {
+        // every load is issued (from a clamped, valid row) and the result dropped afterwards when
+        // the point does not exist: a branch around a load would make each one wait for the last
+        int q, i, l;
+        point_of(j, q, i, l);
+        const int qi = c * GPB + q;
+        const bool have = q < GPB && qi < qb_n;
+        const int64_t row = (static_cast<int64_t>(b) * Lq + qb0 + (have ? qi : 0)) * M + m;
+        float x, y, a;
+        load_point(loc, attn, row, i, rs, x, y, a);
+        px[c * KPC + j] = have ? x : -4.f;  // outside every level: no footprint
+        py[c * KPC + j] = have ? y : -4.f;
+        pa[c * KPC + j] = have ? a : 0.f;
+      }
+  }
+  MSDA_STAMP(1);  // point loads issued
 
   if (MODE == 1 && !(kAblate & 1)) {
     // ---- count the records of this workgroup per destination tile ----
     for (int t = threadIdx.x; t < plan.n_tiles; t += 256) tile_cnt[t] = 0;
     __syncthreads();
-    const int npts = qb_n * LP;
-    const float inv_LP = 1.0f / static_cast<float>(LP), inv_P = 1.0f / static_cast<float>(P);
-    for (int t = threadIdx.x; t < npts; t += 256) {
-      int g, i, l, p_unused;
-      small_divmod(t, LP, inv_LP, g, i);
-      small_divmod(i, P, inv_P, l, p_unused);
-      const LevelInfo L_ = lv[l];
-      const int64_t row = (static_cast<int64_t>(b) * Lq + qb0 + g) * M + m;
-      float x, y, a;
-      load_point(loc, attn, row, i, rs, x, y, a);
-      const Footprint<float> f = footprint<float>(x, y, L_.H, L_.W);
-      if (f.any && a != 0.f) {
-        uint32_t tiles[4];
-        bool keep[4];
-        footprint_tiles(f, plan, tm, L_, l, tiles, keep);
+    MSDA_STAMP(2);  // counters zeroed
+    if constexpr (KPC > 0) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          if (keep[j]) atomicAdd(&tile_cnt[tiles[j]], 1u);
+      for (int k = 0; k < PRE; ++k) {
+        int q, i, l;
+        point_of(k % KPC, q, i, l);
+        const LevelInfo L_ = lv[l];
+        const Footprint<float> f = footprint<float>(px[k], py[k], L_.H, L_.W);
+        if (f.any && pa[k] != 0.f) {
+          uint32_t tiles[4];
+          bool keep[4];
+          footprint_tiles(f, plan, tm, L_, l, tiles, keep);
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (keep[j]) atomicAdd(&tile_cnt[tiles[j]], 1u);
+        }
+      }
+    } else {
+      const int npts = qb_n * LP;
+      const float inv_LP = 1.0f / static_cast<float>(LP), inv_P = 1.0f / static_cast<float>(P);
+      for (int t = threadIdx.x; t < npts; t += 256) {
+        int g, i, l, p_unused;
+        small_divmod(t, LP, inv_LP, g, i);
+        small_divmod(i, P, inv_P, l, p_unused);
+        const LevelInfo L_ = lv[l];
+        const int64_t row = (static_cast<int64_t>(b) * Lq + qb0 + g) * M + m;
+        float x, y, a;
+        load_point(loc, attn, row, i, rs, x, y, a);
+        const Footprint<float> f = footprint<float>(x, y, L_.H, L_.W);
+        if (f.any && a != 0.f) {
+          uint32_t tiles[4];
+          bool keep[4];
+          footprint_tiles(f, plan, tm, L_, l, tiles, keep);
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (keep[j]) atomicAdd(&tile_cnt[tiles[j]], 1u);
+        }
       }
     }
     __syncthreads();
+    MSDA_STAMP(3);  // count pass (waits for the point loads)
     // directory row of this workgroup: (offset, count) per tile, then ranks restart from 0
     const int64_t slab = static_cast<int64_t>(b) * M + m;
     uint2* dir_row = dir + (slab * plan.n_qblocks + qblock) * plan.n_tiles;
     for (int t = threadIdx.x; t < plan.n_tiles; t += 256) tile_off[t] = tile_cnt[t];
-    block_exclusive_scan(tile_off, plan.n_tiles, scan_tmp);
+    const uint32_t n_records = block_exclusive_scan(tile_off, plan.n_tiles, scan_tmp);
     for (int t = threadIdx.x; t < plan.n_tiles; t += 256) {
       dir_row[t] = make_uint2(tile_off[t], tile_cnt[t]);
       tile_cnt[t] = 0;
@@ -627,7 +782,54 @@ __global__ __launch_bounds__(256) void bwd_query_kernel(
     emit.tile_cnt = tile_cnt;
     emit.plan = plan;
     emit.tm = &tm;
+    emit.lds_image = nullptr;
+    emit.lds_cap = 0;
+    if constexpr (KPC > 0 && MSDA_K3_LDS_EMIT) {
+      // the staging and parking areas are still free: they hold the head of the record region
+      emit.lds_image = stage;
+      emit.lds_cap = static_cast<uint32_t>(stage_total + (NCHUNK - 1) * KPC * 3 * 256 * 4 / 16);
+    }
     __syncthreads();
+    MSDA_STAMP(4);  // scan + directory row
+    if constexpr (KPC > 0) {
+      // all records of the workgroup now, while its points are in registers.  They are sorted by
+      // tile as they are placed (offset of the tile + rank), first into an LDS image of the
+      // region, which then goes out as one linear copy of whole 16-byte lanes: a record store
+      // issued per point lands in 64 different lines per wave instruction.  Records beyond the
+      // image (uniformly scattered locations produce more) are stored directly.
+#pragma unroll
+      for (int k = 0; k < PRE; ++k) {
+        int q, i, l;
+        point_of(k % KPC, q, i, l);
+        const LevelInfo L_ = lv[l];
+        const Footprint<float> f = footprint<float>(px[k], py[k], L_.H, L_.W);
+        emit_records(f, L_, l, px[k], py[k], pa[k], qb0 + (k / KPC) * GPB + q, emit);
+      }
+      if (emit.lds_cap > 0) {
+        __syncthreads();
+        const uint32_t n_copy = min(n_records, min(emit.lds_cap, plan.region));
+        for (uint32_t t = threadIdx.x; t < n_copy; t += 256) emit.records[t] = emit.lds_image[t];
+        __syncthreads();
+      }
+      // then the points of the second and third chunk are parked in LDS (the gather loop needs
+      // the registers) and the first chunk is staged
+#pragma unroll
+      for (int k = KPC; k < PRE; ++k) {
+        stash[((k - KPC) * 3 + 0) * 256 + threadIdx.x] = px[k];
+        stash[((k - KPC) * 3 + 1) * 256 + threadIdx.x] = py[k];
+        stash[((k - KPC) * 3 + 2) * 256 + threadIdx.x] = pa[k];
+      }
+      const int stride = group_stride_slots(LPB, SL);
+      const int nq0 = min(GPB, qb_n);
+#pragma unroll
+      for (int j = 0; j < KPC; ++j) {
+        int q, i, l;
+        point_of(j, q, i, l);
+        if (q < nq0)
+          stage_point<KIND, false>(lv[l], l, px[j], py[j], pa[j], qb0 + q,
+                                   stage + q * stride + SL * i, rowb, headb, emit);
+      }
+    }
   }
 
   const int g = threadIdx.x / GQ, lane = threadIdx.x % GQ;
@@ -641,9 +843,15 @@ __global__ __launch_bounds__(256) void bwd_query_kernel(
   for (int ib = 0; ib < LP; ib += LPB) {
     const int nq = min(GPB, qb_n - c0);
     const int nI = min(LPB, LP - ib);
-    stage_chunk<LT, KIND, MODE == 1>(lv, loc, attn, stage, b, qb0 + c0, nq, m, M, Lq, LP, P, ib,
-                                     nI, LPB, rowb, headb, rs, emit);
+    if constexpr (KPC > 0) {
+      // staged already: the first chunk by the prologue, the others behind the previous gather
+    } else {
+      stage_chunk<LT, KIND, MODE == 1>(lv, loc, attn, stage, b, qb0 + c0, nq, m, M, Lq, LP, P, ib,
+                                       nI, LPB, rowb, headb, rs, emit);
+    }
+    MSDA_STAMP(5);  // staging + record emit (own share)
     __syncthreads();
+    MSDA_STAMP(6);  // barrier behind the staging
     // lanes of groups past the end redo the last group (no writes) so that every DPP row is full
     const bool live = g < nq;
     const int gg = live ? g : nq - 1;
@@ -662,7 +870,102 @@ __global__ __launch_bounds__(256) void bwd_query_kernel(
         Chunk<VT>::store(reinterpret_cast<char*>(g_copy) + hm_row * D * sizeof(VT) +
                              (lane + j * GQ) * 16, go[j]);
     }
+    MSDA_STAMP(7);  // grad_out row load (+ copy store issue)
 
+    if constexpr (MODE == 1 && MSDA_K3_DEPTH == 2) {
+      // Two points in flight: the eight row loads of point i + 1 are issued before the dot
+      // products of point i are taken, so a lane always has 8-16 loads outstanding instead of
+      // 0-8 (the kernel runs at 3 waves per SIMD: what hides the gather latency is the number of
+      // loads each wave keeps in flight).  The rows come in through a buffer descriptor of the
+      // batch element's value slab: one 32-bit offset register per load, and an offset outside
+      // the slab reads zeros instead of faulting.
+      typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+      const uint32_t slab_bytes = static_cast<uint32_t>(S) * M * D * sizeof(VT);
+      const __amdgpu_buffer_rsrc_t vres = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<char*>(vb), 0, static_cast<int>(slab_bytes), 0x00020000);
+      struct PointRegs {
+        uint4 orr, fr;
+        u32x4 raw[4][NC];
+      };
+      const auto issue = [&](int i, PointRegs& pr) {
+        pr.orr = r[SL * i + SL - 2];
+        pr.fr = r[SL * i + SL - 1];
+        const uint32_t oraw[4] = {pr.orr.x, pr.orr.y, pr.orr.z, pr.orr.w};
+#pragma unroll
+        for (int c4 = 0; c4 < 4; ++c4)
+#pragma unroll
+          for (int j = 0; j < NC; ++j)
+            pr.raw[c4][j] = __builtin_amdgcn_raw_buffer_load_b128(
+                vres, static_cast<int>((oraw[c4] & ~15u) + lane_b + j * GQ * 16), 0, 0);
+      };
+      float keep_sv = 0.f, keep_sx = 0.f, keep_sy = 0.f;
+      const auto consume = [&](const PointRegs& pr, int k) {
+        const uint32_t oraw[4] = {pr.orr.x, pr.orr.y, pr.orr.z, pr.orr.w};
+        const float lx = __uint_as_float(pr.fr.x), ly = __uint_as_float(pr.fr.y);
+        const float aW = __uint_as_float(pr.fr.z), aH = __uint_as_float(pr.fr.w);
+        const float hx = 1.f - lx, hy = 1.f - ly;
+        float dot[4];
+#pragma unroll
+        for (int c4 = 0; c4 < 4; ++c4) {
+          float d = 0.f;
+#pragma unroll
+          for (int j = 0; j < NC; ++j) {
+            float v[CPL];
+            Chunk<VT>::unpack(__builtin_bit_cast(uint4, pr.raw[c4][j]), v);
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) d = fmaf(go[j][c], v[c], d);
+          }
+          dot[c4] = (oraw[c4] & 1u) ? d : 0.f;  // a corner outside the level contributes nothing
+        }
+        // w = {hy*hx, hy*lx, ly*hx, ly*lx}; dw/dx = {-hy, hy, -ly, ly}; dw/dy = {-hx, -lx, hx, lx}
+        float sv = hy * fmaf(hx, dot[0], lx * dot[1]) + ly * fmaf(hx, dot[2], lx * dot[3]);
+        float sx = fmaf(hy, dot[1] - dot[0], ly * (dot[3] - dot[2]));
+        float sy = fmaf(hx, dot[2] - dot[0], lx * (dot[3] - dot[1]));
+        sv = group_sum<GQ>(sv);
+        sx = group_sum<GQ>(sx);
+        sy = group_sum<GQ>(sy);
+        if (lane == k) {
+          keep_sv = sv;
+          keep_sx = aW * sx;
+          keep_sy = aH * sy;
+        }
+      };
+      // four points per pass whatever the group width: lane j < 4 of the group keeps the results
+      // of point i0 + j (with 8 or 16 lanes per query a pass of that many points would be partly
+      // empty for 12 points per query)
+      constexpr int PP = 4;
+      PointRegs pa_, pb_;
+      issue(0, pa_);
+      for (int i0 = 0; i0 < nI; i0 += PP) {
+        // a pass past the end redoes the last point (results unused)
+#pragma unroll
+        for (int k = 0; k < PP; k += 2) {
+          issue(min(i0 + k + 1, nI - 1), pb_);
+          __builtin_amdgcn_sched_barrier(0);
+          consume(pa_, k);
+          __builtin_amdgcn_sched_barrier(0);
+          if (k + 2 < PP) {
+            issue(min(i0 + k + 2, nI - 1), pa_);
+          } else if (i0 + PP < nI) {
+            issue(i0 + PP, pa_);  // first point of the next pass
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          consume(pb_, k + 1);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        const int i = i0 + lane;
+        if (lane < PP && i < nI && live && !(kAblate & 2)) {
+          Elem<LT>::store(grad_attn + triple * rs.attn + ib + i, keep_sv);
+          LT* gl = grad_loc + triple * rs.loc + 2 * (ib + i);
+          if constexpr (sizeof(LT) == 4) {
+            *reinterpret_cast<float2*>(gl) = make_float2(keep_sx, keep_sy);
+          } else {
+            Elem<LT>::store(gl, keep_sx);
+            Elem<LT>::store(gl + 1, keep_sy);
+          }
+        }
+      }
+    } else {
     // GQ points per pass: after the pass lane j of the group keeps the results of point i0 + j,
     // so the group writes GQ consecutive grad_attn / grad_loc elements with one store each
     for (int i0 = 0; i0 < nI; i0 += GQ) {
@@ -746,8 +1049,31 @@ __global__ __launch_bounds__(256) void bwd_query_kernel(
         }
       }
     }
+    }
+    MSDA_STAMP(8);  // gather + dot products + gradient stores
     __syncthreads();
+    MSDA_STAMP(9);  // barrier behind the gather
+    if constexpr (KPC > 0) {
+      // the next chunk's points come back from where this thread parked them
+      const int cn = c0 / GPB + 1;
+      const int nqn = min(GPB, qb_n - cn * GPB);
+      if (nqn > 0) {
+        const int stride = group_stride_slots(LPB, SL);
+#pragma unroll
+        for (int j = 0; j < KPC; ++j) {
+          int q, i, l;
+          point_of(j, q, i, l);
+          const float x = stash[(((cn - 1) * KPC + j) * 3 + 0) * 256 + threadIdx.x];
+          const float y = stash[(((cn - 1) * KPC + j) * 3 + 1) * 256 + threadIdx.x];
+          const float a = stash[(((cn - 1) * KPC + j) * 3 + 2) * 256 + threadIdx.x];
+          if (q < nqn)
+            stage_point<KIND, false>(lv[l], l, x, y, a, qb0 + cn * GPB + q,
+                                     stage + q * stride + SL * i, rowb, headb, emit);
+        }
+      }
+    }
   }
+  MSDA_STAMP_FLUSH(0);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -793,6 +1119,7 @@ __global__ __launch_bounds__(256) void bwd_tile_gather_kernel(
   const int m = blockIdx.x % M;
   const int tile = plan.n_tiles - 1 - blockIdx.x / M;  // coarse (record-heavy) levels first
   const int64_t slab = static_cast<int64_t>(b) * M + m;
+  MSDA_STAMP_DECL;
   if (threadIdx.x < L) lv[threadIdx.x] = load_level(shapes, lsi, threadIdx.x, S);
   if (threadIdx.x == 0) n_runs_s = 0;
   if (threadIdx.x < TS) cnt[threadIdx.x] = 0;
@@ -816,6 +1143,7 @@ __global__ __launch_bounds__(256) void bwd_tile_gather_kernel(
   const uint32_t total = block_exclusive_scan(run_first, n_runs, scan_tmp);
   if (threadIdx.x == 0) run_first[n_runs] = total;
   __syncthreads();
+  MSDA_STAMP(0);  // level table, directory column, run scan
 
   const uint4* slab_records = records + slab * plan.n_qblocks * static_cast<int64_t>(plan.region);
   // grad_out rows of this head: (N, Lq, M, D) as given, or the per-head copy (N, M, Lq, D)
@@ -867,7 +1195,9 @@ __global__ __launch_bounds__(256) void bwd_tile_gather_kernel(
         rloc[j] = packed;
       }
     }
+    MSDA_STAMP(1);  // A: record loads, footprints, counts (own share)
     __syncthreads();
+    MSDA_STAMP(2);  // barrier behind A
     // ---- B: exclusive scan of the 64 per-position counts by wave 0; cnt becomes the cursor ----
     if (threadIdx.x < TS) {
       const uint32_t c = cnt[threadIdx.x];
@@ -877,6 +1207,7 @@ __global__ __launch_bounds__(256) void bwd_tile_gather_kernel(
       if (threadIdx.x == TS - 1) start[TS] = incl;
     }
     __syncthreads();
+    MSDA_STAMP(3);  // B: scan
     // ---- C: fill the buckets ----
 #pragma unroll
     for (int j = 0; j < RPT; ++j) {
@@ -889,7 +1220,9 @@ __global__ __launch_bounds__(256) void bwd_tile_gather_kernel(
         }
       }
     }
+    MSDA_STAMP(4);  // C: fill (own share)
     __syncthreads();
+    MSDA_STAMP(5);  // barrier behind C
     if (threadIdx.x < TS) cnt[threadIdx.x] = 0;  // ready for the next round
     // ---- D: walk the bucket of this lane group's position ----
     if (!(kAblate & 8)) {
@@ -918,9 +1251,12 @@ __global__ __launch_bounds__(256) void bwd_tile_gather_kernel(
         accumulate(w_cur, rv_cur);
       }
     }
+    MSDA_STAMP(6);  // D: walk (own share)
     __syncthreads();
+    MSDA_STAMP(7);  // barrier behind D
   }
 
+  MSDA_STAMP_FLUSH(1);
   // store the position of this lane group: lane pl holds chunks pl, pl + 4, ... of the row
   int64_t pos;
   if (plan.tile2d) {
@@ -1177,7 +1513,14 @@ int tuned_backward_typed(const void* grad_out, const void* value, const int64_t*
   const bool binned =
       allow_binned && make_bin_plan(N, S, M, D, Lq, L, P, levels_host, &plan, &dir_b, &rec_b);
   const int slots = stage_slots(binned ? kStageBwdBinned : kStageBwdAtomic);
-  const int LPB = stage_points_per_pass(GQ, LP, slots);
+  int LPB = stage_points_per_pass(GQ, LP, slots);
+  // Register-resident points (see bwd_query_kernel): 4 lanes per query, three chunks of 64
+  // queries per workgroup, up to 16 points per query staged in one pass (34 KB of LDS at 16).
+  int kpc = 0;
+  if (MSDA_K3_PRE && binned && plan.qb == 192 && LP <= 16) {
+    kpc = GQ == 4 ? (LP <= 12 ? 3 : 4) : 2;  // ceil(GPB * LP / 256), rounded up to a built variant
+    LPB = LP;
+  }
   hipError_t e;
 
   if (binned) {
@@ -1187,7 +1530,8 @@ int tuned_backward_typed(const void* grad_out, const void* value, const int64_t*
                              : static_cast<VT*>(nullptr);
     const dim3 qgrid(static_cast<unsigned>(plan.n_qblocks) * M, N);
     const size_t qlds = static_cast<size_t>(GPB) * group_stride_slots(LPB, slots) * 16 +
-                        static_cast<size_t>(plan.n_tiles) * 8;
+                        (static_cast<size_t>(2 * plan.n_tiles + 3) / 4) * 16 +
+                        (kpc ? static_cast<size_t>((192 / GPB - 1) * kpc) * 3 * 256 * 4 : 0);  // parked points
     const dim3 tgrid(static_cast<unsigned>(plan.n_tiles) * M, N);
     const size_t TSz = static_cast<size_t>(1) << plan.ts_shift;
     // Rounds of 512 records (2 per thread) and 3 entries per walk step (2 for rows of 16 chunks):
@@ -1203,20 +1547,33 @@ int tuned_backward_typed(const void* grad_out, const void* value, const int64_t*
                      g_copy ? static_cast<const VT*>(g_copy) : static_cast<const VT*>(grad_out), \
                      shapes, lsi, records, dir, static_cast<VT*>(grad_value), S, M, Lq, L, plan, \
                      g_copy ? 1 : 0)
-#define MSDA_TB(GG)                                                                              \
-  hipLaunchKernelGGL((bwd_query_kernel<VT, LT, GG, 1>), qgrid, dim3(256), qlds, stream,          \
+#define MSDA_TQ(GG, KK)                                                                          \
+  hipLaunchKernelGGL((bwd_query_kernel<VT, LT, GG, 1, KK>), qgrid, dim3(256), qlds, stream,      \
                      static_cast<const VT*>(grad_out), static_cast<const VT*>(value), shapes,    \
                      lsi, static_cast<const LT*>(loc), static_cast<const LT*>(attn),             \
                      static_cast<LT*>(grad_loc), static_cast<LT*>(grad_attn),                    \
                      static_cast<float*>(nullptr), records, dir, g_copy, S, M, Lq, L, P, LPB,    \
-                     head_major ? 1 : 0, rs, plan);                                              \
-  MSDA_TILE(GG, RPT, (GG >= 16 ? 2 : 3))
+                     head_major ? 1 : 0, rs, plan)
+#define MSDA_TB(GG, UU)                                                                          \
+  if (kpc == 0) {                                                                                \
+    MSDA_TQ(GG, 0);                                                                              \
+  } else if (query_lanes(GG) == 4) {                                                             \
+    if (kpc == 3) {                                                                              \
+      MSDA_TQ(GG, (query_lanes(GG) == 4 ? 3 : 2));                                               \
+    } else {                                                                                     \
+      MSDA_TQ(GG, (query_lanes(GG) == 4 ? 4 : 2));                                               \
+    }                                                                                            \
+  } else {                                                                                       \
+    MSDA_TQ(GG, 2);                                                                              \
+  }                                                                                              \
+  MSDA_TILE(GG, RPT, UU)
     switch (G) {
-      case 4: MSDA_TB(4); break;
-      case 8: MSDA_TB(8); break;
-      default: MSDA_TB(16); break;
+      case 4: MSDA_TB(4, 3); break;
+      case 8: MSDA_TB(8, 3); break;
+      default: MSDA_TB(16, 2); break;
     }
 #undef MSDA_TB
+#undef MSDA_TQ
 #undef MSDA_TILE
     e = hipGetLastError();
     return e == hipSuccess ? 0 : static_cast<int>(e);
