@@ -38,12 +38,13 @@ host = (ctypes.c_int64 * (2 * l))(*[int(x) for x in shapes.flatten().tolist()])
 vt = torch.empty((n, m, s, d), dtype=value.dtype, device="cuda")
 out = torch.empty((n, lq, m * d), dtype=value.dtype, device="cuda")
 gv = torch.empty_like(value); gl = torch.empty_like(loc); ga = torch.empty_like(attn)
-HM = 8
+HM = 0 if os.environ.get('NOHM') else 8
+if not HM: vt = value
 ws = None
 def run(lib, what):
     global ws
     st = torch.cuda.current_stream().cuda_stream
-    if what in ("relayout", "all"):
+    if what in ("relayout", "all") and HM:
         lib.msda_value_relayout(value.data_ptr(), vt.data_ptr(), n, s, m, d, dv, 1, st)
     if what in ("fwd", "all"):
         rc = lib.msda_forward(vt.data_ptr(), shapes.data_ptr(), lsi.data_ptr(), loc.data_ptr(), attn.data_ptr(), out.data_ptr(), n, s, m, d, lq, l, p, dv, dl, HM, st); assert rc == 0, rc

@@ -154,6 +154,7 @@ struct LevelInfo {
   int H, W, start;
 };
 
+
 // A level whose extent does not fit inside [0, S) gets H = W = 0: no address derived from it can
 // leave the value tensor, and its points contribute nothing.
 __device__ __forceinline__ LevelInfo load_level(const int64_t* __restrict__ shapes,
@@ -1110,8 +1111,8 @@ __global__ __launch_bounds__(256) void bwd_tile_gather_kernel(
   __shared__ int tile_level_s, tile_y0_s, tile_x0_s;
 
   uint2* entries = reinterpret_cast<uint2*>(lds);                    // 4 * R
-  uint32_t* cnt = reinterpret_cast<uint32_t*>(entries + 4 * R);      // TS: counts, then cursors
-  uint32_t* start = cnt + TS;                                        // TS + 1
+  uint32_t* cnt2 = reinterpret_cast<uint32_t*>(entries + 4 * R);     // 2 x TS: counts, then cursors
+  uint32_t* start = cnt2 + 2 * TS;                                   // TS + 1
   uint32_t* run_first = start + TS + 1;                              // n_qblocks + 1
   uint32_t* run_base = run_first + plan.n_qblocks + 1;               // n_qblocks
 
@@ -1122,7 +1123,7 @@ __global__ __launch_bounds__(256) void bwd_tile_gather_kernel(
   MSDA_STAMP_DECL;
   if (threadIdx.x < L) lv[threadIdx.x] = load_level(shapes, lsi, threadIdx.x, S);
   if (threadIdx.x == 0) n_runs_s = 0;
-  if (threadIdx.x < TS) cnt[threadIdx.x] = 0;
+  if (threadIdx.x < 2 * TS) cnt2[threadIdx.x] = 0;
   __syncthreads();
   if (plan.tile2d && threadIdx.x == 0) {
     build_tile_map(lv, L, plan, tm);
@@ -1159,23 +1160,36 @@ __global__ __launch_bounds__(256) void bwd_tile_gather_kernel(
 #pragma unroll
     for (int c = 0; c < CPL; ++c) sum[j][c] = 0.f;
 
-  for (uint32_t base = 0; base < total; base += R) {
+  // The two count arrays alternate between rounds: a round's counts are cleared during the scan
+  // of the round before, so a wave that has finished its walk starts on the next round's records
+  // (phase A: registers and the other count array only) while slower waves still walk, without a
+  // barrier at the end of the round.
+  int parity = 0;
+  for (uint32_t base = 0; base < total; base += R, parity ^= 1) {
+    uint32_t* cnt = cnt2 + parity * TS;
     // ---- A: this thread's records of the round: footprints, count the in-tile corners ----
     uint32_t rq[RPT];
     uint32_t rloc[RPT];  // 4 bytes: position inside the tile per corner, 0xff = not in this tile
     float rw[RPT][4];
+    uint4 recs[RPT];
+    // every record load is issued before the first is used (index clamped into the tile's list)
+#pragma unroll
+    for (int j = 0; j < RPT; ++j) {
+      const uint32_t i = min(base + j * 256 + threadIdx.x, total - 1);
+      int lo = 0, hi = n_runs;  // run_first[lo] <= i < run_first[hi]
+      while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (run_first[mid] <= i) lo = mid; else hi = mid;
+      }
+      recs[j] = slab_records[run_base[lo] + (i - run_first[lo])];
+    }
 #pragma unroll
     for (int j = 0; j < RPT; ++j) {
       const uint32_t i = base + j * 256 + threadIdx.x;
       rloc[j] = 0xffffffffu;
       rq[j] = 0;
       if (i < total && !(kAblate & 32)) {
-        int lo = 0, hi = n_runs;  // run_first[lo] <= i < run_first[hi]
-        while (hi - lo > 1) {
-          const int mid = (lo + hi) >> 1;
-          if (run_first[mid] <= i) lo = mid; else hi = mid;
-        }
-        const uint4 rec = slab_records[run_base[lo] + (i - run_first[lo])];
+        const uint4 rec = recs[j];
         const int l = static_cast<int>(rec.x >> 28);
         const LevelInfo L_ = lv[l];
         const float a = __uint_as_float(rec.y);
@@ -1205,6 +1219,7 @@ __global__ __launch_bounds__(256) void bwd_tile_gather_kernel(
       start[threadIdx.x] = incl - c;
       cnt[threadIdx.x] = incl - c;
       if (threadIdx.x == TS - 1) start[TS] = incl;
+      cnt2[(parity ^ 1) * TS + threadIdx.x] = 0;  // the next round's counts
     }
     __syncthreads();
     MSDA_STAMP(3);  // B: scan
@@ -1223,7 +1238,6 @@ __global__ __launch_bounds__(256) void bwd_tile_gather_kernel(
     MSDA_STAMP(4);  // C: fill (own share)
     __syncthreads();
     MSDA_STAMP(5);  // barrier behind C
-    if (threadIdx.x < TS) cnt[threadIdx.x] = 0;  // ready for the next round
     // ---- D: walk the bucket of this lane group's position ----
     if (!(kAblate & 8)) {
       const uint32_t e0 = start[pg], e1 = start[pg + 1];
@@ -1252,8 +1266,8 @@ __global__ __launch_bounds__(256) void bwd_tile_gather_kernel(
       }
     }
     MSDA_STAMP(6);  // D: walk (own share)
-    __syncthreads();
-    MSDA_STAMP(7);  // barrier behind D
+    // no barrier here: the next round's phase A touches nothing this round's walk reads, and
+    // the barrier behind it orders the next scan and fill after every wave's walk
   }
 
   MSDA_STAMP_FLUSH(1);
@@ -1540,7 +1554,7 @@ int tuned_backward_typed(const void* grad_out, const void* value, const int64_t*
     // CU): headline shapes 1.11 -> 1.01 ms, and no slower with 4 levels x 8 points or in bf16;
     // rounds of 768 or 256 records and 2 / 4 / 6 / 8 entries per step are all slower.
     constexpr int RPT = 2;
-    const size_t tlds = 4 * 256 * static_cast<size_t>(RPT) * 8 + (2 * TSz + 1) * 4 +
+    const size_t tlds = 4 * 256 * static_cast<size_t>(RPT) * 8 + (3 * TSz + 1) * 4 +
                         (2 * static_cast<size_t>(plan.n_qblocks) + 1) * 4;
 #define MSDA_TILE(GG, RR, UU)                                                                    \
   hipLaunchKernelGGL((bwd_tile_gather_kernel<VT, GG, RR, UU>), tgrid, dim3(256), tlds, stream,   \
