@@ -129,10 +129,14 @@ int msda_packed_points_supported(int N, int S, int M, int D, int Lq, int L, int 
 /*
  * Copies value between the two layouts: to_head_major != 0: src (N,S,M,D) -> dst (N,M,S,D);
  * to_head_major == 0: the reverse.  D * element size must be a multiple of 16 bytes and both
- * pointers 16-byte aligned.  No counterpart in the reference (see above).
+ * pointers 16-byte aligned.  `padding_mask` is optional (NULL allowed): N * S bytes, device
+ * memory; the rows of a position whose byte is non-zero are written as zeros — the
+ * `masked_fill(padding_mask, 0)` of the layer that calls the op, done in the same pass, so that
+ * the value projection's output reaches the per-head layout, masked, in one epilogue pass.  No
+ * counterpart in the reference (see above).
  */
-int msda_value_relayout(const void* src, void* dst, int N, int S, int M, int D, int dtype_val,
-                        int to_head_major, void* hip_stream);
+int msda_value_relayout(const void* src, void* dst, const unsigned char* padding_mask, int N,
+                        int S, int M, int D, int dtype_val, int to_head_major, void* hip_stream);
 
 /*
  * Scratch the backward needs, in bytes (0 when none).  The binned grad_value path keeps its

@@ -138,6 +138,62 @@ def test_fused_layer_matches_unfused():
         assert (x - y).abs().max().item() / scale <= 2e-4
 
 
+def test_value_epilogue_head_major_with_padding_mask():
+    """The value projection's epilogue pass: per-head layout and padding mask together."""
+    from unipercept_amd.deform_attn import _function
+
+    g = torch.Generator(device="cuda").manual_seed(11)
+    for dtype in (torch.float32, torch.bfloat16):
+        value = torch.randn(2, 777, 8, 32, generator=g, device="cuda").to(dtype)
+        mask = torch.rand(2, 777, generator=g, device="cuda") < 0.3
+        got = torch.ops.unipercept.ms_deform_attn_value_head_major(value, mask)
+        want = value.masked_fill(mask[..., None, None], 0.0).permute(0, 2, 1, 3).contiguous()
+        assert torch.equal(got, want)
+        assert torch.equal(torch.ops.unipercept.ms_deform_attn_value_head_major(value), value.permute(0, 2, 1, 3).contiguous())
+    v = torch.randn(2, 50, 8, 32, generator=g, device="cuda", requires_grad=True)
+    mask = torch.rand(2, 50, generator=g, device="cuda") < 0.3
+    out = _function.HeadMajorValueFunction.apply(v, mask)
+    grad = torch.randn(2, 50, 8, 32, generator=g, device="cuda")
+    out.backward(grad.permute(0, 2, 1, 3))  # the op hands its position-major gradient on as a view
+    assert torch.equal(v.grad, grad.masked_fill(mask[..., None, None], 0.0))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_fused_layer_with_padding_mask_matches_unfused(dtype):
+    """Layer with a padding mask: the fused route (one projection for offsets and logits, point
+    epilogue, value epilogue with the mask, packed kernels on the caller-made per-head copy)
+    against the plain route (masked_fill, separate projections, op-made copy)."""
+    from unipercept_amd.deform_attn import MSDeformAttn
+
+    torch.manual_seed(7)
+    levels = [(32, 64), (16, 32), (8, 16)]
+    shapes = torch.as_tensor(levels, dtype=torch.long, device="cuda")
+    lsi = torch.cat((shapes.new_zeros((1,)), shapes.prod(1).cumsum(0)[:-1]))
+    s = int(shapes.prod(1).sum())
+    layer = MSDeformAttn(d_model=256, n_levels=3, n_heads=8, n_points=4).cuda().to(dtype)
+    torch.nn.init.normal_(layer.sampling_offsets.weight, std=0.02)
+    torch.nn.init.normal_(layer.attention_weights.weight, std=0.05)
+    feats = torch.randn(2, s, 256, device="cuda").to(dtype)
+    ref = torch.rand(2, s, 3, 2, device="cuda")
+    target = torch.randn(2, s, 256, device="cuda").to(dtype)
+    mask = torch.zeros(2, s, dtype=torch.bool, device="cuda")
+    mask[1, s // 3 :] = True
+
+    def run(fused: bool):
+        layer.fused_points = fused
+        layer.zero_grad()
+        x = feats.clone().requires_grad_(True)
+        out = layer(x, ref, x, shapes, lsi, mask)
+        (out * target).sum().backward()
+        return [out.detach(), x.grad] + [p.grad.clone() for p in layer.parameters()]
+
+    a, b = run(True), run(False)
+    tol = 2e-4 if dtype == torch.float32 else 2.0**-5
+    for x, y in zip(a, b):
+        scale = y.float().abs().max().item() + 1e-30
+        assert (x.float() - y.float()).abs().max().item() / scale <= tol
+
+
 def test_fused_layer_keeps_fp32_locations_under_autocast():
     """Under bf16 autocast the projections run in bf16; the fused path must still hand the
     kernels fp32 locations and weights (a bf16 location near 1.0 has a resolution of 1/256, a

@@ -45,7 +45,7 @@ def run(lib, what):
     global ws
     st = torch.cuda.current_stream().cuda_stream
     if what in ("relayout", "all") and HM:
-        lib.msda_value_relayout(value.data_ptr(), vt.data_ptr(), n, s, m, d, dv, 1, st)
+        lib.msda_value_relayout(value.data_ptr(), vt.data_ptr(), None, n, s, m, d, dv, 1, st)
     if what in ("fwd", "all"):
         rc = lib.msda_forward(vt.data_ptr(), shapes.data_ptr(), lsi.data_ptr(), loc.data_ptr(), attn.data_ptr(), out.data_ptr(), n, s, m, d, lq, l, p, dv, dl, HM, st); assert rc == 0, rc
     if what in ("bwd", "all"):

@@ -14,7 +14,7 @@ host = (ctypes.c_int64 * (2 * l))(*[int(x) for x in shapes.flatten().tolist()])
 vt = torch.empty((n, m, s, d), dtype=value.dtype, device="cuda")
 gv = torch.empty_like(value); gl = torch.empty_like(loc); ga = torch.empty_like(attn)
 st = torch.cuda.current_stream().cuda_stream
-lib.msda_value_relayout(value.data_ptr(), vt.data_ptr(), n, s, m, d, dv, 1, st)
+lib.msda_value_relayout(value.data_ptr(), vt.data_ptr(), None, n, s, m, d, dv, 1, st)
 nb = lib.msda_backward_workspace_bytes(n, s, m, d, lq, l, p, dv, dl, 8, host)
 ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
 for _ in range(3):

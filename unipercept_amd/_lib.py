@@ -10,7 +10,7 @@ from pathlib import Path
 _PKG = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ.get("MSDA_LIBRARY", _PKG / "libmsda.so"))
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 # dtype codes of include/msda.h
 F32, F64, BF16, F16 = 0, 1, 2, 3
@@ -64,7 +64,7 @@ def _declare(lib: ctypes.CDLL) -> None:
     lib.msda_packed_points_supported.restype = c_int
     lib.msda_packed_points_supported.argtypes = [c_int] * 9
     lib.msda_value_relayout.restype = c_int
-    lib.msda_value_relayout.argtypes = [c_vp, c_vp] + [c_int] * 6 + [c_vp]
+    lib.msda_value_relayout.argtypes = [c_vp, c_vp, c_vp] + [c_int] * 6 + [c_vp]
     lib.msda_backward_workspace_bytes.restype = c_sz
     lib.msda_backward_workspace_bytes.argtypes = [c_int] * 7 + [c_int, c_int, c_int, c_vp]
     lib.msda_backward.restype = c_int

@@ -14,7 +14,7 @@ namespace {
 
 using namespace msda;
 
-constexpr int kAbiVersion = 6;
+constexpr int kAbiVersion = 7;
 
 inline size_t elem_size(int dtype) {
   switch (dtype) {
@@ -273,8 +273,8 @@ int msda_packed_points_supported(int N, int S, int M, int D, int Lq, int L, int 
              : 0;
 }
 
-int msda_value_relayout(const void* src, void* dst, int N, int S, int M, int D, int dtype_val,
-                        int to_head_major, void* hip_stream) {
+int msda_value_relayout(const void* src, void* dst, const unsigned char* padding_mask, int N,
+                        int S, int M, int D, int dtype_val, int to_head_major, void* hip_stream) {
   if (!src || !dst) return MSDA_ENULL;
   if (N < 1 || S < 1 || M < 1 || D < 1) return MSDA_ESHAPE;
   const size_t e = elem_size(dtype_val);
@@ -288,8 +288,8 @@ int msda_value_relayout(const void* src, void* dst, int N, int S, int M, int D, 
   // to head-major: src (N,S,M,.) -> dst (N,M,S,.); back: src (N,M,S,.) -> dst (N,S,M,.)
   hipLaunchKernelGGL(relayout_rows_kernel, dim3(grid), dim3(256), 0,
                      static_cast<hipStream_t>(hip_stream), static_cast<const uint4*>(src),
-                     static_cast<uint4*>(dst), rows, to_head_major ? S : M, to_head_major ? M : S,
-                     chunks);
+                     static_cast<uint4*>(dst), padding_mask, rows, to_head_major ? S : M,
+                     to_head_major ? M : S, chunks, to_head_major ? 1 : 0);
   return launch_status();
 }
 

@@ -100,6 +100,13 @@ struct Chunk<float> {
     v[0] = __uint_as_float(t.x); v[1] = __uint_as_float(t.y);
     v[2] = __uint_as_float(t.z); v[3] = __uint_as_float(t.w);
   }
+  // acc + <a, b> over the chunk's elements
+  __device__ __forceinline__ static float dot(const uint4& a, const uint4& b, float acc) {
+    acc = fmaf(__uint_as_float(a.x), __uint_as_float(b.x), acc);
+    acc = fmaf(__uint_as_float(a.y), __uint_as_float(b.y), acc);
+    acc = fmaf(__uint_as_float(a.z), __uint_as_float(b.z), acc);
+    return fmaf(__uint_as_float(a.w), __uint_as_float(b.w), acc);
+  }
   __device__ __forceinline__ static void store(void* p, const float (&v)[4]) {
     *static_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
   }
@@ -118,6 +125,15 @@ struct Chunk<bf16_t> {
   }
   __device__ __forceinline__ static void load(const void* p, float (&v)[8]) {
     unpack(*static_cast<const uint4*>(p), v);
+  }
+  // acc + <a, b>: both operands stay packed, one v_dot2_f32_bf16 (two exact products, fp32
+  // accumulation) per pair instead of two unpacks and an FMA per element
+  __device__ __forceinline__ static float dot(const uint4& a, const uint4& b, float acc) {
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, a.x), __builtin_bit_cast(bf16x2, b.x), acc, false);
+    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, a.y), __builtin_bit_cast(bf16x2, b.y), acc, false);
+    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, a.z), __builtin_bit_cast(bf16x2, b.z), acc, false);
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, a.w), __builtin_bit_cast(bf16x2, b.w), acc, false);
   }
   __device__ __forceinline__ static void store(void* p, const float (&v)[8]) {
     uint32_t w[4];
@@ -141,6 +157,13 @@ struct Chunk<f16_t> {
     const half8 t = __builtin_bit_cast(half8, r);
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] = static_cast<float>(t[i]);
+  }
+  __device__ __forceinline__ static float dot(const uint4& a, const uint4& b, float acc) {
+    typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+    acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(half2v, a.x), __builtin_bit_cast(half2v, b.x), acc, false);
+    acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(half2v, a.y), __builtin_bit_cast(half2v, b.y), acc, false);
+    acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(half2v, a.z), __builtin_bit_cast(half2v, b.z), acc, false);
+    return __builtin_amdgcn_fdot2(__builtin_bit_cast(half2v, a.w), __builtin_bit_cast(half2v, b.w), acc, false);
   }
   __device__ __forceinline__ static void store(void* p, const float (&v)[8]) {
     half8 t;
@@ -859,17 +882,20 @@ __global__ __launch_bounds__(256, MSDA_K3_MINWAVES) void bwd_query_kernel(
     const uint4* r = stage + gg * group_stride_slots(LPB, SL);
     const int64_t triple = (static_cast<int64_t>(b) * Lq + qb0 + c0 + gg) * M + m;
     float go[NC][CPL];
+    uint4 go_raw[NC];  // the same chunks as loaded (16-bit types: still packed)
 #pragma unroll
-    for (int j = 0; j < NC; ++j)
-      Chunk<VT>::load(reinterpret_cast<const char*>(grad_out) + triple * D * sizeof(VT) +
-                          (lane + j * GQ) * 16, go[j]);
+    for (int j = 0; j < NC; ++j) {
+      go_raw[j] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(grad_out) +
+                                                  triple * D * sizeof(VT) + (lane + j * GQ) * 16);
+      Chunk<VT>::unpack(go_raw[j], go[j]);
+    }
     if (g_copy != nullptr && ib == 0 && live) {
       // the row again, where the tile kernel will look for it: (batch, head, query) order
       const int64_t hm_row = (static_cast<int64_t>(b) * M + m) * Lq + qb0 + c0 + gg;
 #pragma unroll
       for (int j = 0; j < NC; ++j)
-        Chunk<VT>::store(reinterpret_cast<char*>(g_copy) + hm_row * D * sizeof(VT) +
-                             (lane + j * GQ) * 16, go[j]);
+        *reinterpret_cast<uint4*>(reinterpret_cast<char*>(g_copy) + hm_row * D * sizeof(VT) +
+                                  (lane + j * GQ) * 16) = go_raw[j];
     }
     MSDA_STAMP(7);  // grad_out row load (+ copy store issue)
 
@@ -910,12 +936,8 @@ __global__ __launch_bounds__(256, MSDA_K3_MINWAVES) void bwd_query_kernel(
         for (int c4 = 0; c4 < 4; ++c4) {
           float d = 0.f;
 #pragma unroll
-          for (int j = 0; j < NC; ++j) {
-            float v[CPL];
-            Chunk<VT>::unpack(__builtin_bit_cast(uint4, pr.raw[c4][j]), v);
-#pragma unroll
-            for (int c = 0; c < CPL; ++c) d = fmaf(go[j][c], v[c], d);
-          }
+          for (int j = 0; j < NC; ++j)
+            d = Chunk<VT>::dot(go_raw[j], __builtin_bit_cast(uint4, pr.raw[c4][j]), d);
           dot[c4] = (oraw[c4] & 1u) ? d : 0.f;  // a corner outside the level contributes nothing
         }
         // w = {hy*hx, hy*lx, ly*hx, ly*lx}; dw/dx = {-hy, hy, -ly, ly}; dw/dy = {-hx, -lx, hx, lx}
@@ -1420,10 +1442,14 @@ inline bool head_major_supported(int N, int S, int M, int D, int Lq, int L, int 
          make_bin_plan(N, S, M, D, Lq, L, P, nullptr, &plan, &a, &b);
 }
 
-// (N,S,M,D) <-> (N,M,S,D): rows of D*e bytes move whole, 16 bytes per lane
+// (N,S,M,D) <-> (N,M,S,D): rows of D*e bytes move whole, 16 bytes per lane.  `mask` (n, S) bytes,
+// optional: rows of a position whose byte is non-zero are written as zeros (the padding mask of
+// the layer, applied in the same pass); the position is index a of the source when `pos_is_a`.
 __global__ __launch_bounds__(256) void relayout_rows_kernel(const uint4* __restrict__ src,
-                                                           uint4* __restrict__ dst, int64_t rows,
-                                                           int A, int B, int chunks) {
+                                                           uint4* __restrict__ dst,
+                                                           const unsigned char* __restrict__ mask,
+                                                           int64_t rows, int A, int B, int chunks,
+                                                           int pos_is_a) {
   // src is (n, A, B, chunks), dst is (n, B, A, chunks)
   const int64_t total = rows * chunks;
   const int64_t stride = static_cast<int64_t>(gridDim.x) * 256;
@@ -1433,7 +1459,9 @@ __global__ __launch_bounds__(256) void relayout_rows_kernel(const uint4* __restr
     const int a = static_cast<int>(row % A);
     const int bb = static_cast<int>(row / A % B);
     const int64_t n = row / A / B;
-    dst[i] = src[((n * A + a) * B + bb) * chunks + c];
+    uint4 v = src[((n * A + a) * B + bb) * chunks + c];
+    if (mask != nullptr && mask[pos_is_a ? n * A + a : n * B + bb]) v = make_uint4(0u, 0u, 0u, 0u);
+    dst[i] = v;
   }
 }
 

@@ -146,7 +146,10 @@ class MultiScaleFlashAttnFunction(torch.autograd.Function):
         level_start_index: torch.Tensor,
         packed: torch.Tensor,
         im2col_step: int = 64,
+        value_head_major: bool = False,
     ) -> torch.Tensor:
+        """``value_head_major``: ``value`` is already the per-head copy (N, M, S, D) (made by
+        ``HeadMajorValueFunction``); its gradient then has that shape too."""
         levels = int(spatial_shapes.shape[0])
         if packed.dim() != 4 or packed.shape[-1] % (3 * levels) != 0:
             raise ValueError(
@@ -162,6 +165,17 @@ class MultiScaleFlashAttnFunction(torch.autograd.Function):
         )
         loc = packed[..., : 2 * lp].reshape(n, lq, m, levels, points, 2)  # a view when possible
         fflags = forward_flags()
+        ctx.value_head_major = bool(value_head_major)
+        if value_head_major:
+            # the caller made the per-head copy: only the packed-points kernels take it
+            ctx.direct, ctx.head_major = True, True
+            fflags |= _lib.FLAG_VALUE_HEAD_MAJOR
+            ctx.bwd_flags = _lib.FLAG_VALUE_HEAD_MAJOR | (
+                _lib.FLAG_TILE_1D if os.environ.get("MSDA_TILE_1D") == "1" else 0
+            )
+            out = _ops.ms_flash_attn_fwd(value, spatial_shapes, level_start_index, packed, fflags)
+            ctx.save_for_backward(value, spatial_shapes, level_start_index, packed)
+            return out
         bflags = backward_flags(value, loc)
         ctx.direct = (
             os.environ.get("MSDA_NO_PACKED_POINTS") != "1"
@@ -192,13 +206,40 @@ class MultiScaleFlashAttnFunction(torch.autograd.Function):
             grad_value, grad_packed = _ops.ms_flash_attn_bwd(
                 grad_output, value, spatial_shapes, level_start_index, packed, ctx.bwd_flags
             )
-            return grad_value, None, None, grad_packed, None
+            if ctx.value_head_major:
+                # grad_value is produced position-major (N,S,M,D), the layout the projection's
+                # weight- and input-gradient GEMMs want; seen through the input's (N,M,S,D) shape
+                grad_value = grad_value.permute(0, 2, 1, 3)
+            return grad_value, None, None, grad_packed, None, None
         value, spatial_shapes, level_start_index, loc, attn = ctx.saved_tensors
         grad_value, grad_loc, grad_attn = _ops.ms_deform_attn_bwd(
             grad_output, value, spatial_shapes, level_start_index, loc, attn, ctx.bwd_flags
         )
         grad_packed = torch.cat((grad_loc.flatten(-3), grad_attn.flatten(-2)), dim=-1)
-        return grad_value, None, None, grad_packed, None
+        return grad_value, None, None, grad_packed, None, None
+
+
+class HeadMajorValueFunction(torch.autograd.Function):
+    """Epilogue of the value projection: ``(N,S,M,D) -> (N,M,S,D)`` with the padding mask applied
+    in the same pass (one HIP row copy instead of ``masked_fill`` + a re-layout inside the op).
+    The result goes to ``MultiScaleFlashAttnFunction(..., value_head_major=True)``.  Backward: the
+    incoming gradient is the op's position-major grad_value seen through the (N,M,S,D) shape; it is
+    handed on in (N,S,M,D) with the masked positions zeroed."""
+
+    @staticmethod
+    def forward(ctx, value, padding_mask=None):
+        ctx.save_for_backward(padding_mask) if padding_mask is not None else None
+        ctx.has_mask = padding_mask is not None
+        return _ops.ms_deform_attn_value_head_major(value, padding_mask)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_hm):
+        grad = grad_hm.permute(0, 2, 1, 3)  # contiguous again when it came from the op
+        if ctx.has_mask:
+            (mask,) = ctx.saved_tensors
+            grad = grad.masked_fill(mask[..., None, None], 0.0)
+        return grad.contiguous(), None
 
 
 class SamplingPointsFunction(torch.autograd.Function):

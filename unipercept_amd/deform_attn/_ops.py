@@ -436,8 +436,12 @@ def _(grad_packed, packed, spatial_shapes, raw_dtype):
 
 
 @torch.library.custom_op("unipercept::ms_deform_attn_value_head_major", mutates_args=())
-def ms_deform_attn_value_head_major(value: torch.Tensor) -> torch.Tensor:
-    """(N,S,M,D) -> a new contiguous (N,M,S,D) tensor (one slab per head), by a HIP row copy."""
+def ms_deform_attn_value_head_major(
+    value: torch.Tensor, padding_mask: torch.Tensor | None = None
+) -> torch.Tensor:
+    """(N,S,M,D) -> a new contiguous (N,M,S,D) tensor (one slab per head), by a HIP row copy;
+    positions where the optional boolean ``padding_mask`` (N,S) is set come out as zeros (the
+    layer's ``masked_fill`` in the same pass)."""
     lib = _lib.load()
     if value.dim() != 4 or value.dtype not in _DTYPE_CODE:
         raise ValueError(f"expected a floating (N,S,M,D) tensor, got {tuple(value.shape)} {value.dtype}")
@@ -445,10 +449,16 @@ def ms_deform_attn_value_head_major(value: torch.Tensor) -> torch.Tensor:
         raise RuntimeError("ms_deform_attn_value_head_major runs only on a ROCm GPU")
     value = value.contiguous()
     n, s, m, d = value.shape
+    mask_ptr = None
+    if padding_mask is not None:
+        if tuple(padding_mask.shape) != (n, s):
+            raise ValueError(f"padding_mask must be {(n, s)}, got {tuple(padding_mask.shape)}")
+        padding_mask = padding_mask.to(device=value.device, dtype=torch.bool).contiguous()
+        mask_ptr = padding_mask.data_ptr()
     out = torch.empty((n, m, s, d), dtype=value.dtype, device=value.device)
     with torch.cuda.device_of(value):
         rc = lib.msda_value_relayout(
-            value.data_ptr(), out.data_ptr(), n, s, m, d, _DTYPE_CODE[value.dtype], 1,
+            value.data_ptr(), out.data_ptr(), mask_ptr, n, s, m, d, _DTYPE_CODE[value.dtype], 1,
             _stream_ptr(value.device),
         )
     _lib.check(rc, "msda_value_relayout")
@@ -456,7 +466,7 @@ def ms_deform_attn_value_head_major(value: torch.Tensor) -> torch.Tensor:
 
 
 @ms_deform_attn_value_head_major.register_fake
-def _(value):
+def _(value, padding_mask=None):
     n, s, m, d = value.shape
     return value.new_empty((n, m, s, d))
 

@@ -9,12 +9,14 @@ input_spatial_shapes, input_level_start_index, input_padding_mask=None)``.
 from __future__ import annotations
 
 import math
+import os
 
 import torch
 from torch import nn
 
 from . import _ops
 from ._function import (
+    HeadMajorValueFunction,
     MultiScaleDeformAttnFunction,
     MultiScaleFlashAttnFunction,
     SamplingPointsFunction,
@@ -150,7 +152,8 @@ class MSDeformAttn(nn.Module):
         input_level_start_index: torch.Tensor,
         input_padding_mask: torch.Tensor | None = None,
     ) -> torch.Tensor:
-        value = self.project_value(input_flatten, input_padding_mask)
+        fuse_mask = input_padding_mask is not None and self.fused_points and input_flatten.is_cuda
+        value = self.project_value(input_flatten, None if fuse_mask else input_padding_mask)
         if self.can_fuse_points(query, reference_points, value):
             n, lq, _ = query.shape
             weight, bias = self.fused_projection()
@@ -159,10 +162,26 @@ class MSDeformAttn(nn.Module):
             # projection ran in 16 bits (autocast, .bfloat16()): a bf16 location near 1.0 has a
             # resolution of 1/256, a whole pixel on a 256-wide level
             packed = SamplingPointsFunction.apply(raw, reference_points.float(), input_spatial_shapes)
+            probe = torch.empty(
+                (n, lq, self.n_heads, self.n_levels, self.n_points, 2), dtype=packed.dtype, device="meta"
+            )
+            if os.environ.get("MSDA_NO_HEAD_MAJOR") != "1" and _ops.head_major_supported(value, probe):
+                # epilogue of the value projection: per-head layout + padding mask in one pass;
+                # the op then gathers from that copy in both directions without making its own
+                value_hm = HeadMajorValueFunction.apply(value, input_padding_mask if fuse_mask else None)
+                out = MultiScaleFlashAttnFunction.apply(
+                    value_hm, input_spatial_shapes, input_level_start_index, packed,
+                    self.im2col_step, True,
+                )
+                return self.output_proj(out)
+            if fuse_mask:
+                value = value.masked_fill(input_padding_mask[..., None, None], 0.0)
             out = MultiScaleFlashAttnFunction.apply(
                 value, input_spatial_shapes, input_level_start_index, packed, self.im2col_step
             )
             return self.output_proj(out)
+        if fuse_mask:
+            value = value.masked_fill(input_padding_mask[..., None, None], 0.0)
         locations, weights = self.sampling_points(query, reference_points, input_spatial_shapes)
         out = self.op(
             value, input_spatial_shapes, input_level_start_index, locations, weights,
