@@ -81,6 +81,19 @@ enum {
    * runs of the flattened sequence even when the level shapes are known on the host (for A/B
    * measurements and tests of that geometry). */
   MSDA_FLAG_TILE_1D = 32,
+  /* The points come RAW, as the layer's projection left them: `loc` is one tensor
+   * (N, Lq, M, 3*L*P) holding per (batch, query, head) row the L*P pixel offsets (dx, dy) and then
+   * the L*P attention logits (the packed row form of MSDA_FLAG_PACKED_POINTS), and `ref_points`
+   * (N, Lq, L, 2), fp32, holds the query's reference point on every level.  The kernels compute
+   *     (x, y) = ref + (dx / W_l, dy / H_l),   weights = softmax over the row's L*P logits
+   * as they read the points, and msda_backward writes the gradient of the raw tensor (offsets:
+   * d(x, y) / (W_l, H_l); logits: w_i * (g_i - sum_k w_k g_k)) into `grad_loc`: neither the
+   * locations nor the softmax weights exist as a tensor in either direction.  This is the
+   * arithmetic of the canonical layer around the op (see msda_points_forward); the entry point
+   * of the reference that takes packed points, `MultiScaleFlashAttnFunction`, applies no softmax
+   * (tests/unipercept/nn/layers/test_nn_layers_deform_attn.py:105-122) and is served without
+   * this flag.  Where msda_raw_points_supported() says so; `attn` / `grad_attn` are ignored. */
+  MSDA_FLAG_RAW_POINTS = 64,
 };
 
 /* Library ABI version (bumped when a signature changes or entry points are added). */
@@ -105,11 +118,13 @@ int msda_check_im2col_step(int N, int im2col_step);
  * same as `reference.deform_attn`, same file :40-49).
  *
  * dtype_val in {F32, F64, BF16, F16}; dtype_loc == dtype_val, or F32 with a 16-bit dtype_val.
- * Accumulation is fp32 (fp64 for F64).
+ * Accumulation is fp32 (fp64 for F64).  `ref_points` is only read with MSDA_FLAG_RAW_POINTS
+ * (NULL otherwise).
  */
 int msda_forward(const void* value, const int64_t* shapes_dev, const int64_t* lsi_dev,
-                 const void* loc, const void* attn, void* out, int N, int S, int M, int D, int Lq,
-                 int L, int P, int dtype_val, int dtype_loc, int flags, void* hip_stream);
+                 const void* loc, const void* attn, const void* ref_points, void* out, int N,
+                 int S, int M, int D, int Lq, int L, int P, int dtype_val, int dtype_loc,
+                 int flags, void* hip_stream);
 
 /*
  * 1 when both msda_forward and msda_backward take MSDA_FLAG_VALUE_HEAD_MAJOR for this problem
@@ -125,6 +140,14 @@ int msda_head_major_supported(int N, int S, int M, int D, int Lq, int L, int P, 
  */
 int msda_packed_points_supported(int N, int S, int M, int D, int Lq, int L, int P, int dtype_val,
                                  int dtype_loc);
+
+/*
+ * 1 when msda_forward and msda_backward take MSDA_FLAG_RAW_POINTS for this problem (tuned
+ * kernels, even L*P <= 16, binned backward), else 0; callers then run msda_points_forward /
+ * msda_points_backward around the packed-points form.  `dtype_loc` is the raw tensor's type.
+ */
+int msda_raw_points_supported(int N, int S, int M, int D, int Lq, int L, int P, int dtype_val,
+                              int dtype_loc);
 
 /*
  * Copies value between the two layouts: to_head_major != 0: src (N,S,M,D) -> dst (N,M,S,D);
@@ -168,10 +191,11 @@ size_t msda_backward_workspace_bytes(int N, int S, int M, int D, int Lq, int L, 
  * out-of-bounds access).  The pointer is only read during the call.
  */
 int msda_backward(const void* grad_out, const void* value, const int64_t* shapes_dev,
-                  const int64_t* lsi_dev, const void* loc, const void* attn, void* grad_value,
-                  void* grad_loc, void* grad_attn, void* workspace, size_t workspace_bytes, int N,
-                  int S, int M, int D, int Lq, int L, int P, int dtype_val, int dtype_loc,
-                  int flags, const int64_t* shapes_host, void* hip_stream);
+                  const int64_t* lsi_dev, const void* loc, const void* attn,
+                  const void* ref_points, void* grad_value, void* grad_loc, void* grad_attn,
+                  void* workspace, size_t workspace_bytes, int N, int S, int M, int D, int Lq,
+                  int L, int P, int dtype_val, int dtype_loc, int flags,
+                  const int64_t* shapes_host, void* hip_stream);
 
 /*
  * msda_backward for callers that cannot allocate device memory: code under HIP graph capture,
@@ -196,9 +220,10 @@ int msda_backward(const void* grad_out, const void* value, const int64_t* shapes
  */
 int msda_backward_noalloc(const void* grad_out, const void* value, const int64_t* shapes_dev,
                           const int64_t* lsi_dev, const void* loc, const void* attn,
-                          void* grad_value, void* grad_loc, void* grad_attn, int N, int S, int M,
-                          int D, int Lq, int L, int P, int dtype_val, int dtype_loc, int flags,
-                          const int64_t* shapes_host, void* hip_stream);
+                          const void* ref_points, void* grad_value, void* grad_loc,
+                          void* grad_attn, int N, int S, int M, int D, int Lq, int L, int P,
+                          int dtype_val, int dtype_loc, int flags, const int64_t* shapes_host,
+                          void* hip_stream);
 
 /*
  * Sampling-point epilogue of the layer that calls the op.  `raw` (N, Lq, M, 3*L*P) is the output

@@ -65,8 +65,8 @@ FAKE = 0x1000  # never dereferenced: every call below fails validation first
 
 
 def _fwd(value=FAKE, shapes=FAKE, lsi=FAKE, loc=FAKE, attn=FAKE, out=FAKE,
-         dims=(1, 4, 1, 4, 2, 1, 1), dv=0, dl=0, flags=0):
-    return _lib.load().msda_forward(value, shapes, lsi, loc, attn, out, *dims, dv, dl, flags, None)
+         dims=(1, 4, 1, 4, 2, 1, 1), dv=0, dl=0, flags=0, ref=None):
+    return _lib.load().msda_forward(value, shapes, lsi, loc, attn, ref, out, *dims, dv, dl, flags, None)
 
 
 def test_forward_argument_errors():
@@ -89,8 +89,9 @@ def _bwd(workspace=None, wbytes=0, dims=(2, 64, 2, 32, 64, 1, 2), dv=2, dl=2, fl
              grad_value=FAKE, grad_loc=FAKE, grad_attn=FAKE)
     p.update(kw)
     return _lib.load().msda_backward(
-        p["grad_out"], p["value"], p["shapes"], p["lsi"], p["loc"], p["attn"], p["grad_value"],
-        p["grad_loc"], p["grad_attn"], workspace, wbytes, *dims, dv, dl, flags, None, None,
+        p["grad_out"], p["value"], p["shapes"], p["lsi"], p["loc"], p["attn"], p.get("ref"),
+        p["grad_value"], p["grad_loc"], p["grad_attn"], workspace, wbytes, *dims, dv, dl, flags,
+        None, None,
     )
 
 
@@ -161,8 +162,8 @@ def test_packed_points_flag_arguments():
     lib = _lib.load()
     # with the packed flag `attn` may be NULL; without it that is an error
     dims = (1, 4, 1, 4, 2, 1, 0)  # P = 0 -> the shape check fires after the NULL check passed
-    assert lib.msda_forward(FAKE, FAKE, FAKE, FAKE, None, FAKE, *dims, 0, 0, _lib.FLAG_PACKED_POINTS, None) == -2
-    assert lib.msda_forward(FAKE, FAKE, FAKE, FAKE, None, FAKE, *dims, 0, 0, 0, None) == -1
+    assert lib.msda_forward(FAKE, FAKE, FAKE, FAKE, None, None, FAKE, *dims, 0, 0, _lib.FLAG_PACKED_POINTS, None) == -2
+    assert lib.msda_forward(FAKE, FAKE, FAKE, FAKE, None, None, FAKE, *dims, 0, 0, 0, None) == -1
     ok = lib.msda_packed_points_supported
     assert ok(8, 43008, 8, 32, 43008, 3, 4, _lib.F32, _lib.F32) == 1
     assert ok(8, 43008, 8, 32, 43008, 3, 4, _lib.BF16, _lib.F32) == 1
@@ -176,13 +177,32 @@ def test_no_alloc_backward_limit_is_checked_before_any_device_call():
     """msda_backward_noalloc refuses a problem whose scratch exceeds the static 128 MiB array
     (no GPU needed: the size check comes first), and validates like msda_backward otherwise."""
     lib = _lib.load()
-    args = [FAKE] * 9
+    args = [FAKE] * 6 + [None] + [FAKE] * 3
     headline = (8, 43008, 8, 32, 43008, 3, 4)
     assert lib.msda_backward_workspace_bytes(*headline, 0, 0, 0, None) > 128 << 20
     assert lib.msda_backward_noalloc(*args, *headline, 0, 0, 0, None, None) == -9
     assert b"128 MiB" in lib.msda_error_string(-9)
     cpuref = (1, 10752, 8, 32, 10752, 3, 4)
     assert lib.msda_backward_workspace_bytes(*cpuref, 0, 0, 0, None) <= 128 << 20
+
+
+def test_raw_points_flag_validation():
+    """MSDA_FLAG_RAW_POINTS: needs the reference points, an 8-byte aligned pointer and a shape the
+    register-resident backward covers; the support query says which."""
+    lib = _lib.load()
+    ok = lib.msda_raw_points_supported
+    assert ok(8, 43008, 8, 32, 43008, 3, 4, _lib.F32, _lib.F32) == 1
+    assert ok(16, 21760, 8, 32, 21760, 4, 4, _lib.BF16, _lib.BF16) == 1
+    assert ok(8, 43520, 8, 32, 43520, 4, 8, _lib.F32, _lib.F32) == 0  # 32 points per query
+    assert ok(1, 630, 5, 16, 515, 3, 3, _lib.F32, _lib.F32) == 0  # odd L*P
+    assert ok(1, 640, 2, 30, 5, 2, 2, _lib.F32, _lib.F32) == 0  # no tuned kernel
+    raw = _lib.FLAG_RAW_POINTS
+    big = (8, 43008, 8, 32, 43008, 3, 4)
+    assert _fwd(dims=big, flags=raw, attn=None, ref=None) == -1
+    assert _fwd(dims=big, flags=raw, attn=None, ref=FAKE + 4) == -4
+    assert _fwd(dims=(8, 43520, 8, 32, 43520, 4, 8), flags=raw, attn=None, ref=FAKE) == -8
+    assert _bwd(dims=big, dv=0, dl=0, flags=raw, attn=None, grad_attn=None, ref=None) == -1
+    assert _bwd(dims=big, dv=0, dl=0, flags=raw | _lib.FLAG_ATOMIC_SCATTER, attn=None, grad_attn=None, ref=FAKE) == -8
 
 
 def test_points_epilogue_argument_errors():

@@ -37,7 +37,7 @@ def _both(lib, case, dtype, flags=0):
     gv, gl, ga = outputs()
     rc = lib.msda_backward(
         grad_out.data_ptr(), value.data_ptr(), shapes.data_ptr(), lsi.data_ptr(), loc.data_ptr(),
-        attn.data_ptr(), gv.data_ptr(), gl.data_ptr(), ga.data_ptr(), ws.data_ptr(), need, *dims,
+        attn.data_ptr(), None, gv.data_ptr(), gl.data_ptr(), ga.data_ptr(), ws.data_ptr(), need, *dims,
         dv, dl, flags, host, st,
     )
     assert rc == 0, rc
@@ -46,7 +46,7 @@ def _both(lib, case, dtype, flags=0):
     before = torch.cuda.memory_allocated()
     rc = lib.msda_backward_noalloc(
         grad_out.data_ptr(), value.data_ptr(), shapes.data_ptr(), lsi.data_ptr(), loc.data_ptr(),
-        attn.data_ptr(), gv2.data_ptr(), gl2.data_ptr(), ga2.data_ptr(), *dims, dv, dl, flags,
+        attn.data_ptr(), None, gv2.data_ptr(), gl2.data_ptr(), ga2.data_ptr(), *dims, dv, dl, flags,
         host, st,
     )
     assert rc == 0, rc
@@ -85,8 +85,8 @@ def test_no_alloc_backward_refuses_what_does_not_fit():
     fake = 1 << 20
     # headline shapes: 2.5 GB of scratch
     rc = lib.msda_backward_noalloc(
-        fake, fake, fake, fake, fake, fake, fake, fake, fake, 8, 43008, 8, 32, 43008, 3, 4, 0, 0,
-        0, None, None,
+        fake, fake, fake, fake, fake, fake, None, fake, fake, fake, 8, 43008, 8, 32, 43008, 3, 4,
+        0, 0, 0, None, None,
     )
     assert rc == -9
     assert b"128 MiB" in lib.msda_error_string(rc)

@@ -47,11 +47,11 @@ def run(lib, what):
     if what in ("relayout", "all") and HM:
         lib.msda_value_relayout(value.data_ptr(), vt.data_ptr(), None, n, s, m, d, dv, 1, st)
     if what in ("fwd", "all"):
-        rc = lib.msda_forward(vt.data_ptr(), shapes.data_ptr(), lsi.data_ptr(), loc.data_ptr(), attn.data_ptr(), out.data_ptr(), n, s, m, d, lq, l, p, dv, dl, HM, st); assert rc == 0, rc
+        rc = lib.msda_forward(vt.data_ptr(), shapes.data_ptr(), lsi.data_ptr(), loc.data_ptr(), attn.data_ptr(), None, out.data_ptr(), n, s, m, d, lq, l, p, dv, dl, HM, st); assert rc == 0, rc
     if what in ("bwd", "all"):
         nb = lib.msda_backward_workspace_bytes(n, s, m, d, lq, l, p, dv, dl, HM, host)
         if ws is None or ws.numel() < nb: ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
-        rc = lib.msda_backward(g.data_ptr(), vt.data_ptr(), shapes.data_ptr(), lsi.data_ptr(), loc.data_ptr(), attn.data_ptr(), gv.data_ptr(), gl.data_ptr(), ga.data_ptr(), ws.data_ptr(), ws.numel(), n, s, m, d, lq, l, p, dv, dl, HM, host, st); assert rc == 0, rc
+        rc = lib.msda_backward(g.data_ptr(), vt.data_ptr(), shapes.data_ptr(), lsi.data_ptr(), loc.data_ptr(), attn.data_ptr(), None, gv.data_ptr(), gl.data_ptr(), ga.data_ptr(), ws.data_ptr(), ws.numel(), n, s, m, d, lq, l, p, dv, dl, HM, host, st); assert rc == 0, rc
 def set_env(spec, on):
     env = spec.partition(":")[2]
     if env:

@@ -18,7 +18,7 @@ lib.msda_value_relayout(value.data_ptr(), vt.data_ptr(), None, n, s, m, d, dv, 1
 nb = lib.msda_backward_workspace_bytes(n, s, m, d, lq, l, p, dv, dl, 8, host)
 ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
 for _ in range(3):
-    rc = lib.msda_backward(g.data_ptr(), vt.data_ptr(), shapes.data_ptr(), lsi.data_ptr(), loc.data_ptr(), attn.data_ptr(), gv.data_ptr(), gl.data_ptr(), ga.data_ptr(), ws.data_ptr(), nb, n, s, m, d, lq, l, p, dv, dl, 8, host, st); assert rc == 0
+    rc = lib.msda_backward(g.data_ptr(), vt.data_ptr(), shapes.data_ptr(), lsi.data_ptr(), loc.data_ptr(), attn.data_ptr(), None, gv.data_ptr(), gl.data_ptr(), ga.data_ptr(), ws.data_ptr(), nb, n, s, m, d, lq, l, p, dv, dl, 8, host, st); assert rc == 0
 torch.cuda.synchronize()
 import numpy as np
 G = 1 << 15

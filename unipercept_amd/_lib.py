@@ -10,7 +10,7 @@ from pathlib import Path
 _PKG = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ.get("MSDA_LIBRARY", _PKG / "libmsda.so"))
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 # dtype codes of include/msda.h
 F32, F64, BF16, F16 = 0, 1, 2, 3
@@ -20,6 +20,7 @@ FLAG_ATOMIC_SCATTER = 4
 FLAG_VALUE_HEAD_MAJOR = 8
 FLAG_PACKED_POINTS = 16
 FLAG_TILE_1D = 32
+FLAG_RAW_POINTS = 64
 SAMPLE_BILINEAR, SAMPLE_NEAREST = 0, 1
 
 # every symbol include/msda.h declares
@@ -30,6 +31,7 @@ EXPORTS = (
     "msda_forward",
     "msda_head_major_supported",
     "msda_packed_points_supported",
+    "msda_raw_points_supported",
     "msda_value_relayout",
     "msda_backward_workspace_bytes",
     "msda_backward",
@@ -58,22 +60,24 @@ def _declare(lib: ctypes.CDLL) -> None:
     lib.msda_check_im2col_step.restype = c_int
     lib.msda_check_im2col_step.argtypes = [c_int, c_int]
     lib.msda_forward.restype = c_int
-    lib.msda_forward.argtypes = [c_vp] * 6 + [c_int] * 7 + [c_int, c_int, c_int, c_vp]
+    lib.msda_forward.argtypes = [c_vp] * 7 + [c_int] * 7 + [c_int, c_int, c_int, c_vp]
     lib.msda_head_major_supported.restype = c_int
     lib.msda_head_major_supported.argtypes = [c_int] * 9
     lib.msda_packed_points_supported.restype = c_int
     lib.msda_packed_points_supported.argtypes = [c_int] * 9
+    lib.msda_raw_points_supported.restype = c_int
+    lib.msda_raw_points_supported.argtypes = [c_int] * 9
     lib.msda_value_relayout.restype = c_int
     lib.msda_value_relayout.argtypes = [c_vp, c_vp, c_vp] + [c_int] * 6 + [c_vp]
     lib.msda_backward_workspace_bytes.restype = c_sz
     lib.msda_backward_workspace_bytes.argtypes = [c_int] * 7 + [c_int, c_int, c_int, c_vp]
     lib.msda_backward.restype = c_int
     lib.msda_backward.argtypes = (
-        [c_vp] * 10 + [c_sz] + [c_int] * 7 + [c_int, c_int, c_int, c_vp, c_vp]
+        [c_vp] * 11 + [c_sz] + [c_int] * 7 + [c_int, c_int, c_int, c_vp, c_vp]
     )
     lib.msda_backward_noalloc.restype = c_int
     lib.msda_backward_noalloc.argtypes = (
-        [c_vp] * 9 + [c_int] * 7 + [c_int, c_int, c_int, c_vp, c_vp]
+        [c_vp] * 10 + [c_int] * 7 + [c_int, c_int, c_int, c_vp, c_vp]
     )
 
     lib.msda_points_forward.restype = c_int

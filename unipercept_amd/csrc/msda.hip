@@ -14,7 +14,7 @@ namespace {
 
 using namespace msda;
 
-constexpr int kAbiVersion = 7;
+constexpr int kAbiVersion = 8;
 
 inline size_t elem_size(int dtype) {
   switch (dtype) {
@@ -139,8 +139,9 @@ int bwd_generic(const void* grad_out, const void* value, const int64_t* shapes, 
 inline bool needs_f32_image(int dtype_val) { return dtype_val == MSDA_BF16 || dtype_val == MSDA_F16; }
 
 int backward_impl(const void* grad_out, const void* value, const int64_t* shapes_dev,
-                  const int64_t* lsi_dev, const void* loc, const void* attn, void* grad_value,
-                  void* grad_loc, void* grad_attn, void* workspace, size_t workspace_bytes, int N,
+                  const int64_t* lsi_dev, const void* loc, const void* attn,
+                  const void* ref_points, void* grad_value, void* grad_loc, void* grad_attn,
+                  void* workspace, size_t workspace_bytes, int N,
                   int S, int M, int D, int Lq, int L, int P, int dtype_val, int dtype_loc,
                   int flags, const int64_t* shapes_host, void* hip_stream);
 
@@ -221,10 +222,14 @@ int msda_check_im2col_step(int N, int im2col_step) {
 }
 
 int msda_forward(const void* value, const int64_t* shapes_dev, const int64_t* lsi_dev,
-                 const void* loc, const void* attn, void* out, int N, int S, int M, int D, int Lq,
-                 int L, int P, int dtype_val, int dtype_loc, int flags, void* hip_stream) {
-  const bool packed = (flags & MSDA_FLAG_PACKED_POINTS) != 0;  // then `attn` is not looked at
+                 const void* loc, const void* attn, const void* ref_points, void* out, int N,
+                 int S, int M, int D, int Lq, int L, int P, int dtype_val, int dtype_loc,
+                 int flags, void* hip_stream) {
+  const bool raw = (flags & MSDA_FLAG_RAW_POINTS) != 0;  // raw points come in the packed row form
+  const bool packed = raw || (flags & MSDA_FLAG_PACKED_POINTS) != 0;  // then `attn` is not looked at
   if (!value || !shapes_dev || !lsi_dev || !loc || (!attn && !packed) || !out) return MSDA_ENULL;
+  if (raw && !ref_points) return MSDA_ENULL;
+  if (raw && !aligned(ref_points, 8)) return MSDA_EALIGN;
   const int rc = check_common(N, S, M, D, Lq, L, P, dtype_val, dtype_loc);
   if (rc != MSDA_OK) return rc;
   if (!aligned(value, elem_size(dtype_val)) || !aligned(out, elem_size(dtype_val)) ||
@@ -235,9 +240,11 @@ int msda_forward(const void* value, const int64_t* shapes_dev, const int64_t* ls
   hipStream_t stream = static_cast<hipStream_t>(hip_stream);
 
   if (!(flags & MSDA_FLAG_GENERIC)) {
+    if (raw && !raw_points_supported(N, S, M, D, Lq, L, P, dtype_val, dtype_loc)) return MSDA_ELAYOUT;
     const int t = tuned_forward(value, shapes_dev, lsi_dev, loc, attn, out, N, S, M, D, Lq, L, P,
                                 dtype_val, dtype_loc, (flags & MSDA_FLAG_VALUE_HEAD_MAJOR) != 0,
-                                packed, stream);
+                                packed, raw ? static_cast<const float*>(ref_points) : nullptr,
+                                stream);
     if (t != kNotTuned) return t;
   }
   if ((flags & MSDA_FLAG_VALUE_HEAD_MAJOR) || packed) return MSDA_ELAYOUT;
@@ -271,6 +278,12 @@ int msda_packed_points_supported(int N, int S, int M, int D, int Lq, int L, int 
   return tuned_shape_ok(N, S, M, D, Lq, L, P, dtype_val, dtype_loc, &G) && packed_shape_ok(L, P)
              ? 1
              : 0;
+}
+
+int msda_raw_points_supported(int N, int S, int M, int D, int Lq, int L, int P, int dtype_val,
+                              int dtype_loc) {
+  if (check_common(N, S, M, D, Lq, L, P, dtype_val, dtype_loc) != MSDA_OK) return 0;
+  return raw_points_supported(N, S, M, D, Lq, L, P, dtype_val, dtype_loc) ? 1 : 0;
 }
 
 int msda_value_relayout(const void* src, void* dst, const unsigned char* padding_mask, int N,
@@ -309,18 +322,20 @@ size_t msda_backward_workspace_bytes(int N, int S, int M, int D, int Lq, int L, 
 }
 
 int msda_backward(const void* grad_out, const void* value, const int64_t* shapes_dev,
-                  const int64_t* lsi_dev, const void* loc, const void* attn, void* grad_value,
-                  void* grad_loc, void* grad_attn, void* workspace, size_t workspace_bytes, int N,
+                  const int64_t* lsi_dev, const void* loc, const void* attn,
+                  const void* ref_points, void* grad_value, void* grad_loc, void* grad_attn,
+                  void* workspace, size_t workspace_bytes, int N,
                   int S, int M, int D, int Lq, int L, int P, int dtype_val, int dtype_loc,
                   int flags, const int64_t* shapes_host, void* hip_stream) {
-  return backward_impl(grad_out, value, shapes_dev, lsi_dev, loc, attn, grad_value, grad_loc,
-                       grad_attn, workspace, workspace_bytes, N, S, M, D, Lq, L, P, dtype_val,
-                       dtype_loc, flags, shapes_host, hip_stream);
+  return backward_impl(grad_out, value, shapes_dev, lsi_dev, loc, attn, ref_points, grad_value,
+                       grad_loc, grad_attn, workspace, workspace_bytes, N, S, M, D, Lq, L, P,
+                       dtype_val, dtype_loc, flags, shapes_host, hip_stream);
 }
 
 int msda_backward_noalloc(const void* grad_out, const void* value, const int64_t* shapes_dev,
                           const int64_t* lsi_dev, const void* loc, const void* attn,
-                          void* grad_value, void* grad_loc, void* grad_attn, int N, int S, int M,
+                          const void* ref_points, void* grad_value, void* grad_loc,
+                          void* grad_attn, int N, int S, int M,
                           int D, int Lq, int L, int P, int dtype_val, int dtype_loc, int flags,
                           const int64_t* shapes_host, void* hip_stream) {
   // size check first: a problem beyond the static array is refused before any HIP call
@@ -332,23 +347,29 @@ int msda_backward_noalloc(const void* grad_out, const void* value, const int64_t
     const int rc = noalloc_scratch(&ws);
     if (rc != MSDA_OK) return rc;
   }
-  return backward_impl(grad_out, value, shapes_dev, lsi_dev, loc, attn, grad_value, grad_loc,
-                       grad_attn, ws, need > 0 ? kNoAllocScratchBytes : 0, N, S, M, D, Lq, L, P,
-                       dtype_val, dtype_loc, flags, shapes_host, hip_stream);
+  return backward_impl(grad_out, value, shapes_dev, lsi_dev, loc, attn, ref_points, grad_value,
+                       grad_loc, grad_attn, ws, need > 0 ? kNoAllocScratchBytes : 0, N, S, M, D,
+                       Lq, L, P, dtype_val, dtype_loc, flags, shapes_host, hip_stream);
 }
 
 }  // extern "C"
 
 namespace {
 int backward_impl(const void* grad_out, const void* value, const int64_t* shapes_dev,
-                  const int64_t* lsi_dev, const void* loc, const void* attn, void* grad_value,
-                  void* grad_loc, void* grad_attn, void* workspace, size_t workspace_bytes, int N,
+                  const int64_t* lsi_dev, const void* loc, const void* attn,
+                  const void* ref_points, void* grad_value, void* grad_loc, void* grad_attn,
+                  void* workspace, size_t workspace_bytes, int N,
                   int S, int M, int D, int Lq, int L, int P, int dtype_val, int dtype_loc,
                   int flags, const int64_t* shapes_host, void* hip_stream) {
-  const bool packed = (flags & MSDA_FLAG_PACKED_POINTS) != 0;  // attn / grad_attn not looked at
+  const bool raw = (flags & MSDA_FLAG_RAW_POINTS) != 0;
+  const bool packed = raw || (flags & MSDA_FLAG_PACKED_POINTS) != 0;  // attn / grad_attn not looked at
   if (!grad_out || !value || !shapes_dev || !lsi_dev || !loc || !grad_value || !grad_loc ||
-      (!packed && (!attn || !grad_attn)))
+      (!packed && (!attn || !grad_attn)) || (raw && !ref_points))
     return MSDA_ENULL;
+  if (raw && !aligned(ref_points, 8)) return MSDA_EALIGN;
+  if (raw && ((flags & (MSDA_FLAG_DETERMINISTIC | MSDA_FLAG_GENERIC | MSDA_FLAG_ATOMIC_SCATTER)) ||
+              !raw_points_supported(N, S, M, D, Lq, L, P, dtype_val, dtype_loc)))
+    return MSDA_ELAYOUT;
   const int rc = check_common(N, S, M, D, Lq, L, P, dtype_val, dtype_loc);
   if (rc != MSDA_OK) return rc;
   const size_t ev = elem_size(dtype_val), el = elem_size(dtype_loc);
@@ -371,7 +392,8 @@ int backward_impl(const void* grad_out, const void* value, const int64_t* shapes
                                  grad_loc, grad_attn, workspace, N, S, M, D, Lq, L, P, dtype_val,
                                  dtype_loc, !(flags & MSDA_FLAG_ATOMIC_SCATTER),
                                  (flags & MSDA_FLAG_VALUE_HEAD_MAJOR) != 0, packed,
-                                 (flags & MSDA_FLAG_TILE_1D) ? nullptr : shapes_host, stream);
+                                 (flags & MSDA_FLAG_TILE_1D) ? nullptr : shapes_host,
+                                 raw ? static_cast<const float*>(ref_points) : nullptr, stream);
     if (t != kNotTuned) return t;
   }
   if ((flags & MSDA_FLAG_VALUE_HEAD_MAJOR) || packed) return MSDA_ELAYOUT;

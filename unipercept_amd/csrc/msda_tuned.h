@@ -402,6 +402,30 @@ struct EmitCtx {
 enum StageKind { kStageFwd = 0, kStageBwdAtomic = 1, kStageBwdBinned = 2 };
 __host__ __device__ constexpr int stage_slots(int kind) { return kind == kStageBwdAtomic ? 3 : 2; }
 
+// Raw sampling points: locations and weights still as the layer's projection left them, i.e.
+// per (batch, query, head) row L*P pixel offsets (dx, dy) followed by L*P attention logits, next
+// to the query's reference point on every level (`ref`, (N, Lq, L, 2) fp32):
+//     (x, y) = ref + (dx / W_l, dy / H_l),   weight = softmax over the row's L*P logits.
+// The kernels do this arithmetic as they read the points, so the locations and weights never
+// exist as a tensor.  softmax_stats: (max, 1 / sum of exp(logit - max)) of one row.
+template <typename LT>
+__device__ __forceinline__ float2 softmax_stats(const LT* __restrict__ logits, int LP) {
+  float mx = Elem<LT>::load(logits);
+  for (int i = 1; i < LP; ++i) mx = fmaxf(mx, Elem<LT>::load(logits + i));
+  float sum = 0.f;
+  for (int i = 0; i < LP; ++i) sum += expf(Elem<LT>::load(logits + i) - mx);
+  return make_float2(mx, 1.0f / sum);
+}
+
+// (dx, dy, logit) in x / y / a -> (x, y, weight)
+__device__ __forceinline__ void raw_to_point(const float* __restrict__ ref_ql, const LevelInfo& L_,
+                                             float2 stats, float& x, float& y, float& a) {
+  const float2 rp = *reinterpret_cast<const float2*>(ref_ql);
+  x = fmaf(x, 1.0f / static_cast<float>(L_.W), rp.x);
+  y = fmaf(y, 1.0f / static_cast<float>(L_.H), rp.y);
+  a = expf(a - stats.x) * stats.y;
+}
+
 // Appends the scatter records of one sampling point (footprint f on level l, query index q) to
 // the workgroup's record region: one record per destination tile the footprint touches.
 __device__ __forceinline__ void emit_records(const Footprint<float>& f, const LevelInfo& L_, int l,
@@ -435,7 +459,7 @@ __device__ __forceinline__ void emit_records(const Footprint<float>& f, const Le
 template <int KIND, bool EMIT>
 __device__ __forceinline__ void stage_point(const LevelInfo& L_, int l, float x, float y, float a,
                                             int q, uint4* dst, uint32_t rowb, uint32_t headb,
-                                            const EmitCtx& emit) {
+                                            const EmitCtx& emit, bool raw = false) {
   constexpr int SLOTS = stage_slots(KIND);
   const Footprint<float> f = footprint<float>(x, y, L_.H, L_.W);
   uint4 wrec, orec;
@@ -453,8 +477,10 @@ __device__ __forceinline__ void stage_point(const LevelInfo& L_, int l, float x,
     uint4 frec;
     frec.x = __float_as_uint(f.lx);
     frec.y = __float_as_uint(f.ly);
-    frec.z = __float_as_uint(a * static_cast<float>(L_.W));
-    frec.w = __float_as_uint(a * static_cast<float>(L_.H));
+    // factor of the location gradient: d/d(x, y) carries (W, H); d/d(dx, dy) of raw points does
+    // not (the offset is divided by them), and the weight itself is needed for the logit gradient
+    frec.z = __float_as_uint(raw ? a : a * static_cast<float>(L_.W));
+    frec.w = __float_as_uint(raw ? a : a * static_cast<float>(L_.H));
     dst[SLOTS - 1] = frec;
   }
   if constexpr (EMIT) emit_records(f, L_, l, x, y, a, q, emit);
@@ -466,7 +492,9 @@ __device__ __forceinline__ void stage_chunk(const LevelInfo* lv, const LT* __res
                                             const LT* __restrict__ attn, uint4* stage, int b,
                                             int q_first, int nq, int m, int M, int Lq, int LP,
                                             int P, int i_first, int nI, int LPB, uint32_t rowb,
-                                            uint32_t headb, PointRows rs, const EmitCtx& emit) {
+                                            uint32_t headb, PointRows rs, const EmitCtx& emit,
+                                            const float* __restrict__ ref = nullptr,
+                                            const float2* row_stats = nullptr, int L = 0) {
   // points i_first .. i_first + nI - 1 of every query; LDS lists are laid out for LPB points
   constexpr int SLOTS = stage_slots(KIND);
   const int npts = nq * nI;
@@ -480,8 +508,11 @@ __device__ __forceinline__ void stage_chunk(const LevelInfo* lv, const LT* __res
     const int64_t row = (static_cast<int64_t>(b) * Lq + q_first + g) * M + m;
     float x, y, a;
     load_point(loc, attn, row, i, rs, x, y, a);
+    if (ref != nullptr)
+      raw_to_point(ref + ((static_cast<int64_t>(b) * Lq + q_first + g) * L + l) * 2, lv[l],
+                   row_stats[g], x, y, a);
     stage_point<KIND, EMIT>(lv[l], l, x, y, a, q_first + g, stage + g * stride + SLOTS * ii, rowb,
-                            headb, emit);
+                            headb, emit, ref != nullptr);
   }
 }
 
@@ -505,7 +536,7 @@ __global__ __launch_bounds__(256) void fwd_tuned_kernel(
     const VT* __restrict__ value, const int64_t* __restrict__ shapes,
     const int64_t* __restrict__ lsi, const LT* __restrict__ loc, const LT* __restrict__ attn,
     VT* __restrict__ out, int S, int M, int Lq, int L, int P, int LPB, int head_major,
-    PointRows rs) {
+    PointRows rs, const float* __restrict__ ref) {
   constexpr int CPL = Chunk<VT>::kCPL;
   constexpr int D = G * CPL;
   // one chunk per lane here: two (as in the backward query kernel) measured 20 % slower, the
@@ -523,7 +554,11 @@ __global__ __launch_bounds__(256) void fwd_tuned_kernel(
   const int m = blockIdx.x % M;
   const int q0 = (blockIdx.x / M) * GPB;
   const int nq = min(GPB, Lq - q0);
+  __shared__ float2 row_stats[GPB];  // raw points: softmax statistics of the block's rows
   if (threadIdx.x < L) lv[threadIdx.x] = load_level(shapes, lsi, threadIdx.x, S);
+  if (ref != nullptr && static_cast<int>(threadIdx.x) < nq)
+    row_stats[threadIdx.x] = softmax_stats(
+        attn + ((static_cast<int64_t>(b) * Lq + q0 + threadIdx.x) * M + m) * rs.attn, LP);
   __syncthreads();
 
   // value is (N,S,M,D), or (N,M,S,D) when head_major: bytes between positions / to head m
@@ -548,7 +583,7 @@ __global__ __launch_bounds__(256) void fwd_tuned_kernel(
     const int nI = min(LPB, LP - ib);
     if (ib > 0) __syncthreads();
     stage_chunk<LT, kStageFwd, false>(lv, loc, attn, lds, b, q0, nq, m, M, Lq, LP, P, ib, nI, LPB,
-                                      rowb, headb, rs, EmitCtx{});
+                                      rowb, headb, rs, EmitCtx{}, ref, row_stats, L);
     __syncthreads();
     if (live) {
 #pragma unroll 4
@@ -673,7 +708,7 @@ __global__ __launch_bounds__(256, MSDA_K3_MINWAVES) void bwd_query_kernel(
     const LT* __restrict__ loc, const LT* __restrict__ attn, LT* __restrict__ grad_loc,
     LT* __restrict__ grad_attn, float* __restrict__ gv_acc, uint4* __restrict__ records,
     uint2* __restrict__ dir, VT* __restrict__ g_copy, int S, int M, int Lq, int L, int P, int LPB,
-    int head_major, PointRows rs, BinPlan plan) {
+    int head_major, PointRows rs, BinPlan plan, const float* __restrict__ ref) {
   constexpr int CPL = Chunk<VT>::kCPL;
   constexpr int D = G * CPL;
   constexpr int GQ = query_lanes(G);  // lanes per query
@@ -696,7 +731,15 @@ __global__ __launch_bounds__(256, MSDA_K3_MINWAVES) void bwd_query_kernel(
   const int qb0 = qblock * plan.qb;
   const int qb_n = min(plan.qb, Lq - qb0);
   MSDA_STAMP_DECL;
+  // raw points (KPC > 0 only; the host refuses them elsewhere): softmax statistics of the rows
+  __shared__ float2 row_stats[KPC > 0 ? 192 : 1];
+  const bool raw = KPC > 0 && ref != nullptr;
   if (threadIdx.x < L) lv[threadIdx.x] = load_level(shapes, lsi, threadIdx.x, S);
+  if constexpr (KPC > 0) {
+    if (raw && static_cast<int>(threadIdx.x) < qb_n)
+      row_stats[threadIdx.x] = softmax_stats(
+          attn + ((static_cast<int64_t>(b) * Lq + qb0 + threadIdx.x) * M + m) * rs.attn, L * P);
+  }
   __syncthreads();
   if (MODE == 1 && plan.tile2d) {
     if (threadIdx.x == 0) build_tile_map(lv, L, plan, tm);
@@ -740,6 +783,9 @@ __global__ __launch_bounds__(256, MSDA_K3_MINWAVES) void bwd_query_kernel(
         const int64_t row = (static_cast<int64_t>(b) * Lq + qb0 + (have ? qi : 0)) * M + m;
         float x, y, a;
         load_point(loc, attn, row, i, rs, x, y, a);
+        if (raw)
+          raw_to_point(ref + ((static_cast<int64_t>(b) * Lq + qb0 + (have ? qi : 0)) * L + l) * 2,
+                       lv[l], row_stats[have ? qi : 0], x, y, a);
         px[c * KPC + j] = have ? x : -4.f;  // outside every level: no footprint
         py[c * KPC + j] = have ? y : -4.f;
         pa[c * KPC + j] = have ? a : 0.f;
@@ -851,7 +897,7 @@ __global__ __launch_bounds__(256, MSDA_K3_MINWAVES) void bwd_query_kernel(
         point_of(j, q, i, l);
         if (q < nq0)
           stage_point<KIND, false>(lv[l], l, px[j], py[j], pa[j], qb0 + q,
-                                   stage + q * stride + SL * i, rowb, headb, emit);
+                                   stage + q * stride + SL * i, rowb, headb, emit, raw);
       }
     }
   }
@@ -925,7 +971,10 @@ __global__ __launch_bounds__(256, MSDA_K3_MINWAVES) void bwd_query_kernel(
             pr.raw[c4][j] = __builtin_amdgcn_raw_buffer_load_b128(
                 vres, static_cast<int>((oraw[c4] & ~15u) + lane_b + j * GQ * 16), 0, 0);
       };
-      float keep_sv = 0.f, keep_sx = 0.f, keep_sy = 0.f;
+      float keep_sv = 0.f, keep_sx = 0.f, keep_sy = 0.f, keep_a = 0.f;
+      // raw points: weight and weight gradient of this lane's point of every pass, for the
+      // softmax backward d logit_i = w_i * (g_i - sum_k w_k g_k) once all points are through
+      float ka[4] = {0.f, 0.f, 0.f, 0.f}, kg[4] = {0.f, 0.f, 0.f, 0.f};
       const auto consume = [&](const PointRegs& pr, int k) {
         const uint32_t oraw[4] = {pr.orr.x, pr.orr.y, pr.orr.z, pr.orr.w};
         const float lx = __uint_as_float(pr.fr.x), ly = __uint_as_float(pr.fr.y);
@@ -951,6 +1000,7 @@ __global__ __launch_bounds__(256, MSDA_K3_MINWAVES) void bwd_query_kernel(
           keep_sv = sv;
           keep_sx = aW * sx;
           keep_sy = aH * sy;
+          keep_a = aW;  // raw points stage the weight itself here
         }
       };
       // four points per pass whatever the group width: lane j < 4 of the group keeps the results
@@ -977,8 +1027,17 @@ __global__ __launch_bounds__(256, MSDA_K3_MINWAVES) void bwd_query_kernel(
           __builtin_amdgcn_sched_barrier(0);
         }
         const int i = i0 + lane;
+        if (raw) {
+          const bool mine = lane < PP && i < nI;
+#pragma unroll
+          for (int ps = 0; ps < 4; ++ps)
+            if (i0 == ps * PP) {
+              ka[ps] = mine ? keep_a : 0.f;
+              kg[ps] = mine ? keep_sv : 0.f;
+            }
+        }
         if (lane < PP && i < nI && live && !(kAblate & 2)) {
-          Elem<LT>::store(grad_attn + triple * rs.attn + ib + i, keep_sv);
+          if (!raw) Elem<LT>::store(grad_attn + triple * rs.attn + ib + i, keep_sv);
           LT* gl = grad_loc + triple * rs.loc + 2 * (ib + i);
           if constexpr (sizeof(LT) == 4) {
             *reinterpret_cast<float2*>(gl) = make_float2(keep_sx, keep_sy);
@@ -986,6 +1045,18 @@ __global__ __launch_bounds__(256, MSDA_K3_MINWAVES) void bwd_query_kernel(
             Elem<LT>::store(gl, keep_sx);
             Elem<LT>::store(gl + 1, keep_sy);
           }
+        }
+      }
+      if (raw) {
+        float part = 0.f;
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) part = fmaf(ka[ps], kg[ps], part);
+        const float dot_wg = group_sum<GQ>(part);  // sum_k w_k g_k of the query
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) {
+          const int i = ps * PP + lane;
+          if (lane < PP && i < nI && live && !(kAblate & 2))
+            Elem<LT>::store(grad_attn + triple * rs.attn + ib + i, ka[ps] * (kg[ps] - dot_wg));
         }
       }
     } else {
@@ -1091,7 +1162,7 @@ __global__ __launch_bounds__(256, MSDA_K3_MINWAVES) void bwd_query_kernel(
           const float a = stash[(((cn - 1) * KPC + j) * 3 + 2) * 256 + threadIdx.x];
           if (q < nqn)
             stage_point<KIND, false>(lv[l], l, x, y, a, qb0 + cn * GPB + q,
-                                     stage + q * stride + SL * i, rowb, headb, emit);
+                                     stage + q * stride + SL * i, rowb, headb, emit, raw);
         }
       }
     }
@@ -1442,6 +1513,19 @@ inline bool head_major_supported(int N, int S, int M, int D, int Lq, int L, int 
          make_bin_plan(N, S, M, D, Lq, L, P, nullptr, &plan, &a, &b);
 }
 
+// Whether forward and backward take raw points (offsets + logits + reference points): tuned
+// kernels, the packed row form, the binned backward in its register-resident form.
+inline bool raw_points_supported(int N, int S, int M, int D, int Lq, int L, int P, int dtype_val,
+                                 int dtype_loc) {
+  int G;
+  BinPlan plan;
+  size_t a, b;
+  return MSDA_K3_PRE && MSDA_K3_DEPTH == 2 &&
+         tuned_shape_ok(N, S, M, D, Lq, L, P, dtype_val, dtype_loc, &G) && packed_shape_ok(L, P) &&
+         L * P <= 16 && make_bin_plan(N, S, M, D, Lq, L, P, nullptr, &plan, &a, &b) &&
+         plan.qb == 192;
+}
+
 // (N,S,M,D) <-> (N,M,S,D): rows of D*e bytes move whole, 16 bytes per lane.  `mask` (n, S) bytes,
 // optional: rows of a position whose byte is non-zero are written as zeros (the padding mask of
 // the layer, applied in the same pass); the position is index a of the source when `pos_is_a`.
@@ -1468,7 +1552,8 @@ __global__ __launch_bounds__(256) void relayout_rows_kernel(const uint4* __restr
 template <typename VT, typename LT>
 int tuned_forward_typed(const void* value, const int64_t* shapes, const int64_t* lsi,
                         const void* loc, const void* attn, void* out, int N, int S, int M, int Lq,
-                        int L, int P, int G, bool head_major, bool packed, hipStream_t stream) {
+                        int L, int P, int G, bool head_major, bool packed, const float* ref,
+                        hipStream_t stream) {
   const PointRows rs = packed ? PointRows{3 * L * P, 3 * L * P} : PointRows{2 * L * P, L * P};
   if (packed) attn = static_cast<const LT*>(loc) + 2 * L * P;  // the weights follow the pairs
   const bool pair = fwd_pairs(G, L * P);
@@ -1481,7 +1566,7 @@ int tuned_forward_typed(const void* value, const int64_t* shapes, const int64_t*
   hipLaunchKernelGGL((fwd_tuned_kernel<VT, LT, GG, PP>), grid, dim3(256), lds, stream,          \
                      static_cast<const VT*>(value), shapes, lsi, static_cast<const LT*>(loc),   \
                      static_cast<const LT*>(attn), static_cast<VT*>(out), S, M, Lq, L, P, LPB,   \
-                     head_major ? 1 : 0, rs)
+                     head_major ? 1 : 0, rs, ref)
   switch (G) {
     case 4:
       if (pair) {
@@ -1501,13 +1586,13 @@ int tuned_forward_typed(const void* value, const int64_t* shapes, const int64_t*
 inline int tuned_forward(const void* value, const int64_t* shapes, const int64_t* lsi,
                          const void* loc, const void* attn, void* out, int N, int S, int M, int D,
                          int Lq, int L, int P, int dtype_val, int dtype_loc, bool head_major,
-                         bool packed, hipStream_t stream) {
+                         bool packed, const float* ref, hipStream_t stream) {
   int G;
   if (!tuned_shape_ok(N, S, M, D, Lq, L, P, dtype_val, dtype_loc, &G)) return kNotTuned;
   if (!all_aligned16({value, out})) return kNotTuned;
   if (!pair_aligned(loc, dtype_loc) || (packed && !packed_shape_ok(L, P))) return kNotTuned;
 #define MSDA_ARGS \
-  value, shapes, lsi, loc, attn, out, N, S, M, Lq, L, P, G, head_major, packed, stream
+  value, shapes, lsi, loc, attn, out, N, S, M, Lq, L, P, G, head_major, packed, ref, stream
   if (dtype_val == 0) return tuned_forward_typed<float, float>(MSDA_ARGS);
   if (dtype_val == 2)
     return dtype_loc == 0 ? tuned_forward_typed<bf16_t, float>(MSDA_ARGS)
@@ -1541,7 +1626,8 @@ int tuned_backward_typed(const void* grad_out, const void* value, const int64_t*
                          const int64_t* lsi, const void* loc, const void* attn, void* grad_value,
                          void* grad_loc, void* grad_attn, void* workspace, int N, int S, int M,
                          int D, int Lq, int L, int P, int G, bool allow_binned, bool head_major,
-                         bool packed, const int64_t* levels_host, hipStream_t stream) {
+                         bool packed, const int64_t* levels_host, const float* ref,
+                         hipStream_t stream) {
   const PointRows rs = packed ? PointRows{3 * L * P, 3 * L * P} : PointRows{2 * L * P, L * P};
   if (packed) {  // the weights (and their gradient) follow the pairs inside each packed row
     attn = static_cast<const LT*>(loc) + 2 * L * P;
@@ -1564,6 +1650,8 @@ int tuned_backward_typed(const void* grad_out, const void* value, const int64_t*
     LPB = LP;
   }
   hipError_t e;
+  // raw points are handled by the register-resident form of the query kernel only
+  if (ref != nullptr && (kpc == 0 || MSDA_K3_DEPTH != 2)) return MSDA_TUNED_ELAYOUT;
 
   if (binned) {
     uint2* dir = static_cast<uint2*>(workspace);
@@ -1595,7 +1683,7 @@ int tuned_backward_typed(const void* grad_out, const void* value, const int64_t*
                      lsi, static_cast<const LT*>(loc), static_cast<const LT*>(attn),             \
                      static_cast<LT*>(grad_loc), static_cast<LT*>(grad_attn),                    \
                      static_cast<float*>(nullptr), records, dir, g_copy, S, M, Lq, L, P, LPB,    \
-                     head_major ? 1 : 0, rs, plan)
+                     head_major ? 1 : 0, rs, plan, ref)
 #define MSDA_TB(GG, UU)                                                                          \
   if (kpc == 0) {                                                                                \
     MSDA_TQ(GG, 0);                                                                              \
@@ -1643,7 +1731,8 @@ int tuned_backward_typed(const void* grad_out, const void* value, const int64_t*
                      lsi, static_cast<const LT*>(loc), static_cast<const LT*>(attn),             \
                      static_cast<LT*>(grad_loc), static_cast<LT*>(grad_attn), acc,               \
                      static_cast<uint4*>(nullptr), static_cast<uint2*>(nullptr),                 \
-                     static_cast<VT*>(nullptr), S, M, Lq, L, P, LPB, 0, rs, plan)
+                     static_cast<VT*>(nullptr), S, M, Lq, L, P, LPB, 0, rs, plan,                \
+                     static_cast<const float*>(nullptr))
   switch (G) {
     case 4: MSDA_TB(4); break;
     case 8: MSDA_TB(8); break;
@@ -1669,7 +1758,7 @@ inline int tuned_backward(const void* grad_out, const void* value, const int64_t
                           void* grad_loc, void* grad_attn, void* workspace, int N, int S, int M,
                           int D, int Lq, int L, int P, int dtype_val, int dtype_loc,
                           bool allow_binned, bool head_major, bool packed,
-                          const int64_t* levels_host, hipStream_t stream) {
+                          const int64_t* levels_host, const float* ref, hipStream_t stream) {
   int G;
   if (!tuned_shape_ok(N, S, M, D, Lq, L, P, dtype_val, dtype_loc, &G)) return kNotTuned;
   if (!all_aligned16({value, grad_out, grad_value, workspace})) return kNotTuned;
@@ -1678,7 +1767,7 @@ inline int tuned_backward(const void* grad_out, const void* value, const int64_t
     return kNotTuned;
 #define MSDA_ARGS                                                                               \
   grad_out, value, shapes, lsi, loc, attn, grad_value, grad_loc, grad_attn, workspace, N, S, M, \
-      D, Lq, L, P, G, allow_binned, head_major, packed, levels_host, stream
+      D, Lq, L, P, G, allow_binned, head_major, packed, levels_host, ref, stream
   if (dtype_val == 0) return tuned_backward_typed<float, float>(MSDA_ARGS);
   if (dtype_val == 2)
     return dtype_loc == 0 ? tuned_backward_typed<bf16_t, float>(MSDA_ARGS)

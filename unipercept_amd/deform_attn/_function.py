@@ -219,6 +219,45 @@ class MultiScaleFlashAttnFunction(torch.autograd.Function):
         return grad_value, None, None, grad_packed, None, None
 
 
+class MultiScaleRawPointsAttnFunction(torch.autograd.Function):
+    """``apply(value_head_major (N,M,S,D), spatial_shapes, level_start_index, raw (N,Lq,M,3*L*P),
+    reference_points (N,Lq,L,2)) -> (N, Lq, M*D)``: the op on the output of ONE projection that
+    computes sampling offsets and attention logits together (per row L*P (dx, dy), then L*P
+    logits).  Softmax and ``ref + offset / (W_l, H_l)`` happen inside the attention kernels in both
+    directions; ``value`` is the per-head copy made by ``HeadMajorValueFunction``.  The layer of
+    the canonical pixel decoder, not an entry point of the reference's test module."""
+
+    @staticmethod
+    def forward(ctx, value_hm, spatial_shapes, level_start_index, raw, reference_points):
+        flags = _lib.FLAG_VALUE_HEAD_MAJOR
+        out = _ops.ms_deform_raw_attn_fwd(
+            value_hm, spatial_shapes, level_start_index, raw, reference_points, flags
+        )
+        ctx.save_for_backward(value_hm, spatial_shapes, level_start_index, raw, reference_points)
+        ctx.bwd_flags = flags | (_lib.FLAG_TILE_1D if os.environ.get("MSDA_TILE_1D") == "1" else 0)
+        ctx.ref_needs_grad = reference_points.requires_grad
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_output):
+        value_hm, spatial_shapes, level_start_index, raw, reference_points = ctx.saved_tensors
+        grad_value, grad_raw = _ops.ms_deform_raw_attn_bwd(
+            grad_output, value_hm, spatial_shapes, level_start_index, raw, reference_points,
+            ctx.bwd_flags,
+        )
+        grad_ref = None
+        if ctx.ref_needs_grad:
+            # x = ref + dx / W: d ref = sum over heads and points of d x = W * d(dx)
+            n, lq, m, width = raw.shape
+            levels = int(spatial_shapes.shape[0])
+            lp = width // 3
+            wh = torch.stack((spatial_shapes[:, 1], spatial_shapes[:, 0]), -1).to(grad_raw.device, torch.float32)
+            g = grad_raw[..., : 2 * lp].reshape(n, lq, m, levels, lp // levels, 2).float()
+            grad_ref = (g * wh[None, None, None, :, None, :]).sum(dim=(2, 4)).to(reference_points.dtype)
+        return grad_value.permute(0, 2, 1, 3), None, None, grad_raw, grad_ref
+
+
 class HeadMajorValueFunction(torch.autograd.Function):
     """Epilogue of the value projection: ``(N,S,M,D) -> (N,M,S,D)`` with the padding mask applied
     in the same pass (one HIP row copy instead of ``masked_fill`` + a re-layout inside the op).

@@ -147,7 +147,7 @@ def ms_deform_attn_fwd(
     with torch.cuda.device_of(value):
         rc = lib.msda_forward(
             value.data_ptr(), shapes.data_ptr(), lsi.data_ptr(), loc.data_ptr(), attn.data_ptr(),
-            out.data_ptr(), n, s, m, d, lq, l, p, _DTYPE_CODE[value.dtype], _DTYPE_CODE[loc.dtype],
+            None, out.data_ptr(), n, s, m, d, lq, l, p, _DTYPE_CODE[value.dtype], _DTYPE_CODE[loc.dtype],
             flags, _stream_ptr(value.device),
         )
     _lib.check(rc, "msda_forward")
@@ -194,7 +194,7 @@ def ms_deform_attn_bwd(
         )
         rc = lib.msda_backward(
             grad_output.data_ptr(), value.data_ptr(), shapes.data_ptr(), lsi.data_ptr(),
-            loc.data_ptr(), attn.data_ptr(), grad_value.data_ptr(), grad_loc.data_ptr(),
+            loc.data_ptr(), attn.data_ptr(), None, grad_value.data_ptr(), grad_loc.data_ptr(),
             grad_attn.data_ptr(), workspace.data_ptr() if nbytes else None, nbytes,
             n, s, m, d, lq, l, p, vcode, lcode, flags, levels_host, _stream_ptr(value.device),
         )
@@ -270,7 +270,7 @@ def ms_flash_attn_fwd(
     out = torch.empty((n, lq, m * d), dtype=value.dtype, device=value.device)
     with torch.cuda.device_of(value):
         rc = lib.msda_forward(
-            value.data_ptr(), shapes.data_ptr(), lsi.data_ptr(), packed.data_ptr(), None,
+            value.data_ptr(), shapes.data_ptr(), lsi.data_ptr(), packed.data_ptr(), None, None,
             out.data_ptr(), n, s, m, d, lq, l, p, _DTYPE_CODE[value.dtype],
             _DTYPE_CODE[packed.dtype], flags | _lib.FLAG_PACKED_POINTS, _stream_ptr(value.device),
         )
@@ -317,7 +317,7 @@ def ms_flash_attn_bwd(
         )
         rc = lib.msda_backward(
             grad_output.data_ptr(), value.data_ptr(), shapes.data_ptr(), lsi.data_ptr(),
-            packed.data_ptr(), None, grad_value.data_ptr(), grad_packed.data_ptr(), None,
+            packed.data_ptr(), None, None, grad_value.data_ptr(), grad_packed.data_ptr(), None,
             workspace.data_ptr() if nbytes else None, nbytes,
             n, s, m, d, lq, l, p, vcode, lcode, flags, levels_host, _stream_ptr(value.device),
         )
@@ -329,6 +329,118 @@ def ms_flash_attn_bwd(
 def _(grad_output, value, spatial_shapes, level_start_index, packed, flags):
     gv = value.transpose(1, 2) if flags & _lib.FLAG_VALUE_HEAD_MAJOR else value
     return torch.empty_like(gv, memory_format=torch.contiguous_format), torch.empty_like(packed)
+
+
+def _prepare_raw(value, shapes, lsi, raw, reference_points, head_major: bool):
+    """Raw-points counterpart of `_prepare_packed`: raw (N, Lq, M, 3*L*P) holds offsets and
+    logits, reference_points (N, Lq, L, 2) the reference point per level (handed on in fp32)."""
+    value, shapes, lsi, raw, levels_host = _prepare_packed(value, shapes, lsi, raw, head_major)
+    n, lq, levels = raw.shape[0], raw.shape[1], int(shapes.shape[0])
+    if tuple(reference_points.shape) != (n, lq, levels, 2):
+        raise ValueError(
+            f"reference_points must be {(n, lq, levels, 2)}, got {tuple(reference_points.shape)}"
+        )
+    ref = reference_points.to(device=value.device, dtype=torch.float32).contiguous()
+    return value, shapes, lsi, raw, ref, levels_host
+
+
+@torch.library.custom_op("unipercept::ms_deform_raw_attn_fwd", mutates_args=())
+def ms_deform_raw_attn_fwd(
+    value: torch.Tensor,
+    spatial_shapes: torch.Tensor,
+    level_start_index: torch.Tensor,
+    raw: torch.Tensor,
+    reference_points: torch.Tensor,
+    flags: int,
+) -> torch.Tensor:
+    """Forward on raw points: offsets + logits as the projection left them and the reference
+    points; the kernels do the softmax and the location arithmetic as they read them."""
+    lib = _lib.load()
+    hm = bool(flags & _lib.FLAG_VALUE_HEAD_MAJOR)
+    value, shapes, lsi, raw, ref, _ = _prepare_raw(
+        value, spatial_shapes, level_start_index, raw, reference_points, hm
+    )
+    n, s, m, d, lq, l, p = _packed_dims(value, raw, int(shapes.shape[0]), hm)
+    out = torch.empty((n, lq, m * d), dtype=value.dtype, device=value.device)
+    with torch.cuda.device_of(value):
+        rc = lib.msda_forward(
+            value.data_ptr(), shapes.data_ptr(), lsi.data_ptr(), raw.data_ptr(), None,
+            ref.data_ptr(), out.data_ptr(), n, s, m, d, lq, l, p, _DTYPE_CODE[value.dtype],
+            _DTYPE_CODE[raw.dtype], flags | _lib.FLAG_RAW_POINTS, _stream_ptr(value.device),
+        )
+    _lib.check(rc, "msda_forward (raw points)")
+    return out
+
+
+@ms_deform_raw_attn_fwd.register_fake
+def _(value, spatial_shapes, level_start_index, raw, reference_points, flags):
+    d = value.shape[3]
+    return value.new_empty((raw.shape[0], raw.shape[1], raw.shape[2] * d))
+
+
+@torch.library.custom_op("unipercept::ms_deform_raw_attn_bwd", mutates_args=())
+def ms_deform_raw_attn_bwd(
+    grad_output: torch.Tensor,
+    value: torch.Tensor,
+    spatial_shapes: torch.Tensor,
+    level_start_index: torch.Tensor,
+    raw: torch.Tensor,
+    reference_points: torch.Tensor,
+    flags: int,
+) -> tuple[torch.Tensor, torch.Tensor]:
+    """Backward on raw points: grad_value (N,S,M,D) and the gradient of the raw tensor."""
+    lib = _lib.load()
+    raw_dtype = raw.dtype
+    hm = bool(flags & _lib.FLAG_VALUE_HEAD_MAJOR)
+    value, shapes, lsi, raw, ref, levels_host = _prepare_raw(
+        value, spatial_shapes, level_start_index, raw, reference_points, hm
+    )
+    n, s, m, d, lq, l, p = _packed_dims(value, raw, int(shapes.shape[0]), hm)
+    grad_output = grad_output.to(value.dtype).contiguous()
+    if tuple(grad_output.shape) != (n, lq, m * d):
+        raise ValueError(f"grad_output must be {(n, lq, m * d)}, got {tuple(grad_output.shape)}")
+    grad_value = torch.empty((n, s, m, d), dtype=value.dtype, device=value.device)
+    grad_raw = torch.empty_like(raw)
+    vcode, lcode = _DTYPE_CODE[value.dtype], _DTYPE_CODE[raw.dtype]
+    flags |= _lib.FLAG_RAW_POINTS
+    with torch.cuda.device_of(value):
+        nbytes = lib.msda_backward_workspace_bytes(
+            n, s, m, d, lq, l, p, vcode, lcode, flags, levels_host
+        )
+        workspace = (
+            torch.empty(nbytes, dtype=torch.uint8, device=value.device) if nbytes else None
+        )
+        rc = lib.msda_backward(
+            grad_output.data_ptr(), value.data_ptr(), shapes.data_ptr(), lsi.data_ptr(),
+            raw.data_ptr(), None, ref.data_ptr(), grad_value.data_ptr(), grad_raw.data_ptr(), None,
+            workspace.data_ptr() if nbytes else None, nbytes,
+            n, s, m, d, lq, l, p, vcode, lcode, flags, levels_host, _stream_ptr(value.device),
+        )
+    _lib.check(rc, "msda_backward (raw points)")
+    return grad_value, grad_raw.to(raw_dtype)
+
+
+@ms_deform_raw_attn_bwd.register_fake
+def _(grad_output, value, spatial_shapes, level_start_index, raw, reference_points, flags):
+    gv = value.transpose(1, 2) if flags & _lib.FLAG_VALUE_HEAD_MAJOR else value
+    return torch.empty_like(gv, memory_format=torch.contiguous_format), torch.empty_like(raw)
+
+
+def raw_points_supported(value: torch.Tensor, raw: torch.Tensor, levels: int, head_major: bool = False) -> bool:
+    """Whether the kernels take this raw offsets+logits tensor (softmax and location arithmetic
+    inside the attention kernels)."""
+    if value.dtype not in _DTYPE_CODE or value.dim() != 4 or raw.dim() != 4:
+        return False
+    if levels < 1 or raw.shape[-1] % (3 * levels) != 0:
+        return False
+    n, s, m, d, lq, l, p = _packed_dims(value, raw, levels, head_major)
+    vdt = value.dtype
+    ldt = torch.float32 if raw.dtype == torch.float32 and vdt in (torch.bfloat16, torch.float16) else vdt
+    return bool(
+        _lib.load().msda_raw_points_supported(
+            n, s, m, d, lq, l, p, _DTYPE_CODE[vdt], _DTYPE_CODE[ldt]
+        )
+    )
 
 
 def packed_points_supported(value: torch.Tensor, packed: torch.Tensor, levels: int) -> bool:

@@ -17,6 +17,7 @@ from torch import nn
 from . import _ops
 from ._function import (
     HeadMajorValueFunction,
+    MultiScaleRawPointsAttnFunction,
     MultiScaleDeformAttnFunction,
     MultiScaleFlashAttnFunction,
     SamplingPointsFunction,
@@ -161,14 +162,24 @@ class MSDeformAttn(nn.Module):
             # fp32 reference points make the packed locations and weights fp32 even when the
             # projection ran in 16 bits (autocast, .bfloat16()): a bf16 location near 1.0 has a
             # resolution of 1/256, a whole pixel on a 256-wide level
-            packed = SamplingPointsFunction.apply(raw, reference_points.float(), input_spatial_shapes)
             probe = torch.empty(
-                (n, lq, self.n_heads, self.n_levels, self.n_points, 2), dtype=packed.dtype, device="meta"
+                (n, lq, self.n_heads, self.n_levels, self.n_points, 2), dtype=torch.float32, device="meta"
             )
             if os.environ.get("MSDA_NO_HEAD_MAJOR") != "1" and _ops.head_major_supported(value, probe):
                 # epilogue of the value projection: per-head layout + padding mask in one pass;
                 # the op then gathers from that copy in both directions without making its own
                 value_hm = HeadMajorValueFunction.apply(value, input_padding_mask if fuse_mask else None)
+                if os.environ.get("MSDA_NO_RAW_POINTS") != "1" and _ops.raw_points_supported(
+                    value_hm, raw, self.n_levels, head_major=True
+                ):
+                    # softmax and reference-point arithmetic inside the attention kernels: the
+                    # locations and weights are never written out
+                    out = MultiScaleRawPointsAttnFunction.apply(
+                        value_hm, input_spatial_shapes, input_level_start_index, raw,
+                        reference_points.float(),
+                    )
+                    return self.output_proj(out)
+                packed = SamplingPointsFunction.apply(raw, reference_points.float(), input_spatial_shapes)
                 out = MultiScaleFlashAttnFunction.apply(
                     value_hm, input_spatial_shapes, input_level_start_index, packed,
                     self.im2col_step, True,
@@ -176,6 +187,7 @@ class MSDeformAttn(nn.Module):
                 return self.output_proj(out)
             if fuse_mask:
                 value = value.masked_fill(input_padding_mask[..., None, None], 0.0)
+            packed = SamplingPointsFunction.apply(raw, reference_points.float(), input_spatial_shapes)
             out = MultiScaleFlashAttnFunction.apply(
                 value, input_spatial_shapes, input_level_start_index, packed, self.im2col_step
             )
