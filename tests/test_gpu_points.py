@@ -340,3 +340,31 @@ def test_fused_layer_keeps_fp32_locations_under_autocast():
     err = {k: (v - want).abs().max().item() / scale for k, v in outs.items()}
     for route in ("raw", "epilogue"):
         assert err[route] <= 2.0**-5 and err[route] <= err["unfused"] * 1.5 + 2.0**-8, err
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16", "autocast"])
+def test_token_linear_matches_linear(mode):
+    """The projections' sliced weight-gradient GEMM against nn.functional.linear."""
+    from unipercept_amd.deform_attn.layer import _split_k, token_linear
+
+    torch.manual_seed(1)
+    tokens, c, o = 2 * 43008, 256, 288
+    assert _split_k(tokens) == 64 and _split_k(1000) == 0
+    dt = torch.bfloat16 if mode == "bf16" else torch.float32
+    x = torch.randn(2, 43008, c, device="cuda", dtype=dt)
+    w = (torch.randn(o, c, device="cuda") * 0.05).to(dt)
+    b = torch.randn(o, device="cuda").to(dt)
+    g = torch.randn(2, 43008, o, device="cuda", dtype=dt)
+
+    def run(fn):
+        xx, ww, bb = (t.clone().requires_grad_(True) for t in (x, w, b))
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=mode == "autocast"):
+            out = fn(xx, ww, bb)
+        out.backward(g.to(out.dtype))
+        return out, xx.grad, ww.grad, bb.grad
+
+    got, want = run(token_linear), run(torch.nn.functional.linear)
+    tol = 1e-5 if mode == "f32" else 2.0**-6
+    for a, r in zip(got, want):
+        assert a.dtype == r.dtype and a.shape == r.shape
+        assert (a.float() - r.float()).abs().max().item() <= tol * (r.float().abs().max().item() + 1e-30)

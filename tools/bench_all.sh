@@ -1,7 +1,7 @@
 set -e
-run() { name=$1; shift; timeout -k 10 150 python bench.py --no-cpu-baseline --steps 30 --warmup 5 "$@" > gpurun_out/t7_$name.json 2> gpurun_out/t7_$name.err; python - "$name" <<'PY'
+run() { name=$1; shift; timeout -k 10 150 python bench.py --no-cpu-baseline --steps 30 --warmup 5 "$@" > gpurun_out/r2_$name.json 2> gpurun_out/r2_$name.err; python - "$name" <<'PY'
 import json,sys
-d=json.load(open(f"gpurun_out/t7_{sys.argv[1]}.json")); p=d["phases"]
+d=json.load(open(f"gpurun_out/r2_{sys.argv[1]}.json")); p=d["phases"]
 print(sys.argv[1], round(p["fwd_ms"],3), round(p["bwd_ms"],3), round(d["ms_per_step"],3), round(d["value"]/1e9,2), round(p["step_hbm_frac"]*100,2), flush=True)
 PY
 }

@@ -24,6 +24,66 @@ from ._function import (
 )
 
 
+def _split_k(tokens: int) -> int:
+    """Slices for the weight-gradient GEMM of a projection over `tokens` rows (0: leave it to
+    one GEMM).  The output is only d_model x d_model, so a single GEMM over hundreds of thousands
+    of tokens runs on a few dozen workgroups; as a batched GEMM over slices of the token
+    dimension plus a sum it fills the chip (fp32, 344 064 tokens, 256 x 256: 0.84 -> 0.33 ms on
+    MI355X with 64 slices)."""
+    if tokens < 32768:
+        return 0
+    for sk in (64, 32, 16, 8):
+        if tokens % sk == 0 and tokens // sk >= 1024:
+            return sk
+    return 0
+
+
+class _TokenLinearFunction(torch.autograd.Function):
+    """``F.linear`` for (tokens, features) activations with many tokens: same forward GEMM and
+    input-gradient GEMM, weight gradient by a batched GEMM over slices of the token dimension.
+    Plain PyTorch-ROCm GEMMs throughout."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.in_dtypes = (x.dtype, weight.dtype, bias.dtype)
+        if torch.is_autocast_enabled("cuda"):
+            dt = torch.get_autocast_dtype("cuda")
+            x, weight, bias = x.to(dt), weight.to(dt), bias.to(dt)
+        ctx.save_for_backward(x, weight)
+        return torch.nn.functional.linear(x, weight, bias)
+
+    @staticmethod
+    def backward(ctx, grad):
+        x, weight = ctx.saved_tensors
+        xd, wd, bd = ctx.in_dtypes
+        g2 = grad.reshape(-1, grad.shape[-1]).to(x.dtype)
+        x2 = x.reshape(-1, x.shape[-1])
+        grad_x = grad_w = grad_b = None
+        if ctx.needs_input_grad[0]:
+            grad_x = (g2 @ weight).view_as(x).to(xd)
+        if ctx.needs_input_grad[1]:
+            tokens, sk = x2.shape[0], _split_k(x2.shape[0])
+            if sk:
+                parts = torch.bmm(
+                    g2.view(sk, tokens // sk, -1).transpose(1, 2), x2.view(sk, tokens // sk, -1)
+                )
+                grad_w = parts.sum(0, dtype=torch.float32).to(wd)
+            else:
+                grad_w = (g2.t() @ x2).to(wd)
+        if ctx.needs_input_grad[2]:
+            grad_b = g2.sum(0, dtype=torch.float32).to(bd)
+        return grad_x, grad_w, grad_b
+
+
+def token_linear(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
+    """``F.linear(x, weight, bias)``; on a ROCm device with enough tokens the weight gradient takes
+    the sliced route of ``_TokenLinearFunction``."""
+    tokens = x.numel() // max(x.shape[-1], 1)
+    if x.is_cuda and bias is not None and torch.is_grad_enabled() and _split_k(tokens):
+        return _TokenLinearFunction.apply(x, weight, bias)
+    return torch.nn.functional.linear(x, weight, bias)
+
+
 class MSDeformAttn(nn.Module):
     def __init__(
         self,
@@ -115,7 +175,7 @@ class MSDeformAttn(nn.Module):
 
     def project_value(self, input_flatten, input_padding_mask=None):
         n, s, _ = input_flatten.shape
-        value = self.value_proj(input_flatten)
+        value = token_linear(input_flatten, self.value_proj.weight, self.value_proj.bias)
         if input_padding_mask is not None:
             value = value.masked_fill(input_padding_mask[..., None], 0.0)
         return value.view(n, s, self.n_heads, self.d_model // self.n_heads)
@@ -158,7 +218,7 @@ class MSDeformAttn(nn.Module):
         if self.can_fuse_points(query, reference_points, value):
             n, lq, _ = query.shape
             weight, bias = self.fused_projection()
-            raw = torch.nn.functional.linear(query, weight, bias).view(n, lq, self.n_heads, -1)
+            raw = token_linear(query, weight, bias).view(n, lq, self.n_heads, -1)
             # fp32 reference points make the packed locations and weights fp32 even when the
             # projection ran in 16 bits (autocast, .bfloat16()): a bf16 location near 1.0 has a
             # resolution of 1/256, a whole pixel on a 256-wide level
@@ -178,20 +238,20 @@ class MSDeformAttn(nn.Module):
                         value_hm, input_spatial_shapes, input_level_start_index, raw,
                         reference_points.float(),
                     )
-                    return self.output_proj(out)
+                    return token_linear(out, self.output_proj.weight, self.output_proj.bias)
                 packed = SamplingPointsFunction.apply(raw, reference_points.float(), input_spatial_shapes)
                 out = MultiScaleFlashAttnFunction.apply(
                     value_hm, input_spatial_shapes, input_level_start_index, packed,
                     self.im2col_step, True,
                 )
-                return self.output_proj(out)
+                return token_linear(out, self.output_proj.weight, self.output_proj.bias)
             if fuse_mask:
                 value = value.masked_fill(input_padding_mask[..., None, None], 0.0)
             packed = SamplingPointsFunction.apply(raw, reference_points.float(), input_spatial_shapes)
             out = MultiScaleFlashAttnFunction.apply(
                 value, input_spatial_shapes, input_level_start_index, packed, self.im2col_step
             )
-            return self.output_proj(out)
+            return token_linear(out, self.output_proj.weight, self.output_proj.bias)
         if fuse_mask:
             value = value.masked_fill(input_padding_mask[..., None, None], 0.0)
         locations, weights = self.sampling_points(query, reference_points, input_spatial_shapes)
@@ -199,4 +259,4 @@ class MSDeformAttn(nn.Module):
             value, input_spatial_shapes, input_level_start_index, locations, weights,
             self.im2col_step,
         )
-        return self.output_proj(out)
+        return token_linear(out, self.output_proj.weight, self.output_proj.bias)
