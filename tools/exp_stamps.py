@@ -29,6 +29,15 @@ for which, kname in ((0, "bwd_query_kernel"), (1, "bwd_tile_gather_kernel")):
     lib.msda_debug_read_stamps.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
     got = lib.msda_debug_read_stamps(which, buf, G)
     a = np.frombuffer(buf, dtype=np.uint64).reshape(G, 16).astype(np.float64)
+    if which == 1 and os.environ.get("TILE"):
+        # per level: workgroup (batch, tile*M + head), coarse levels first
+        t = int(os.environ["TILE"]); per = [(-(-h // t)) * (-(-ww // t)) for h, ww in w.levels]
+        gx = sum(per) * m; life = a.sum(1)
+        for lvl in range(len(per)):
+            hi = sum(per[lvl:]) ; lo = sum(per[lvl + 1:])   # reversed tile order
+            idx = [by * gx + bx for by in range(n) for bx in range(lo * m, hi * m) if by * gx + bx < G]
+            sel = life[idx]; sel = sel[sel > 0]
+            if len(sel): print(f"   level {lvl}: {len(sel)} workgroups, lifetime mean {sel.mean():.0f} max {sel.max():.0f}")
     a = a[a.sum(1) > 0]
     tot = a.sum(1)
     print(f"{kname}: {len(a)} workgroups sampled, mean lifetime {tot.mean():.0f} cycles (p10 {np.percentile(tot,10):.0f}, p90 {np.percentile(tot,90):.0f})")

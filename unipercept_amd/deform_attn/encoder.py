@@ -16,7 +16,7 @@ import math
 import torch
 from torch import nn
 
-from .layer import MSDeformAttn
+from .layer import MSDeformAttn, token_linear
 
 
 def sine_position_embedding(
@@ -115,7 +115,8 @@ class MSDeformAttnEncoderLayer(nn.Module):
             query, reference_points, src, spatial_shapes, level_start_index, padding_mask
         )
         src = self.norm1(src + self.dropout(attn))
-        ffn = self.linear2(self.dropout(torch.relu(self.linear1(src))))
+        hidden = torch.relu(token_linear(src, self.linear1.weight, self.linear1.bias))
+        ffn = token_linear(self.dropout(hidden), self.linear2.weight, self.linear2.bias)
         return self.norm2(src + self.dropout(ffn))
 
 
