@@ -251,3 +251,47 @@ def test_points_epilogue_full_size():
     want.backward(grad)
     assert (packed - want).abs().max() <= 2e-6 * want.abs().max()
     assert (grad_raw - raw_t.grad).abs().max() <= 1e-5 * raw_t.grad.abs().max()
+
+
+def test_raw_points_full_size_against_oracle():
+    """The raw-points route (offsets + logits + reference points in, softmax and location
+    arithmetic inside the kernels) on one whole headline-shaped sample: forward and grad_value
+    against the C oracle run on the derived locations / weights, the gradient of the raw tensor
+    against the oracle's grad_loc / grad_attn pushed through the chain rule in fp64."""
+    from unipercept_amd.deform_attn import _function
+
+    w = harness.WORKLOADS["cityscapes_1024x2048_fp32_b8"]
+    value, shapes, lsi, _, _, g = harness.synth_inputs(w, "cuda", batch=1, seed=55)
+    n, s, m, l, p = 1, w.positions, w.heads, w.n_levels, w.points
+    lp = l * p
+    gen = torch.Generator(device="cuda").manual_seed(56)
+    raw = torch.randn(n, s, m, 3 * lp, generator=gen, device="cuda")
+    raw[..., : 2 * lp] *= 4.0  # offsets of a few pixels
+    ref = torch.rand(n, s, l, 2, generator=gen, device="cuda") * 1.02 - 0.01
+    assert _function._ops.raw_points_supported(value, raw, l)
+    v, r, rp = (t.clone().requires_grad_(True) for t in (value, raw, ref))
+    vhm = _function.HeadMajorValueFunction.apply(v)
+    out = _function.MultiScaleRawPointsAttnFunction.apply(vhm, shapes, lsi, r, rp)
+    out.backward(g)
+
+    wh = torch.stack((shapes[:, 1], shapes[:, 0]), -1).double()[None, None, None, :, None, :]
+    off = raw.double()[..., : 2 * lp].reshape(n, s, m, l, p, 2)
+    # the kernels form each location with one fp32 rounding (1 / W is exact for these levels)
+    loc = (ref.double()[:, :, None, :, None, :] + off / wh).float()
+    attn = raw.double()[..., 2 * lp :].softmax(-1).reshape(n, s, m, l, p)
+    w_out, w_gv, w_gl, w_ga = _oracle64(value, shapes, loc, attn, g)
+    assert np.abs(out.detach().cpu().double().numpy() - w_out).max() <= 1e-4
+    assert np.abs(v.grad.cpu().double().numpy() - w_gv).max() <= 1e-3
+    gl, ga = torch.from_numpy(w_gl), torch.from_numpy(w_ga)
+    a = attn.cpu()
+    want_logit = a * (ga - (a * ga).sum(dim=(3, 4), keepdim=True))
+    want_off = gl / wh.cpu()
+    got = r.grad.cpu().double()
+    assert (got[..., 2 * lp :].reshape(n, s, m, l, p) - want_logit).abs().max() <= 1e-3
+    keep = torch.from_numpy(_away_from_pixel_edges(loc, w.levels))[..., None]
+    err = (got[..., : 2 * lp].reshape(n, s, m, l, p, 2) - want_off).abs() * keep
+    assert err.max() <= max(1e-3, 2e-6 * want_off.abs().max().item())
+    # grad of the reference points = sum over heads and points of the location gradients
+    g_loc = got[..., : 2 * lp].reshape(n, s, m, l, p, 2) * wh.cpu()
+    sum_ref = g_loc.sum(dim=(2, 4))
+    assert (rp.grad.cpu().double() - sum_ref).abs().max() <= 1e-4 * sum_ref.abs().max()
