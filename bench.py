@@ -4,10 +4,13 @@
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME] [--dist R|U]
 
 One step = one forward + one backward of the op over one batch of synthetic inputs that already
-sit in HBM.  N > 1 (launched by torch.distributed.run, one rank per GPU) shards the batch: every
-rank runs the same per-GPU workload on its own samples (weak scaling); the only collective is the
-all-reduce of a flat fp32 bucket the size of one MSDeformAttn layer's parameter gradients
-(RCCL), issued on a side stream and overlapped with the next step.
+sit in HBM.  N > 1 shards the batch, one rank per GPU: every rank runs the same per-GPU workload
+on its own samples (weak scaling); the only collective is the all-reduce of a flat fp32 bucket
+the size of one MSDeformAttn layer's parameter gradients (RCCL), issued behind the backward on
+the compute stream (--comm inline, the default) or on a side stream overlapped with the next
+step (--comm overlap).  The ranks come from torch.distributed.run (RANK / WORLD_SIZE in the
+environment) or, for a plain `python bench.py --gpus N`, from this script itself: it starts N
+children before anything touches the GPU and relays rank 0's line.
 
 Rank 0 prints ONE JSON line.
 """

@@ -16,14 +16,14 @@ gv = torch.empty_like(value); gl = torch.empty_like(loc); ga = torch.empty_like(
 st = torch.cuda.current_stream().cuda_stream
 lib.msda_value_relayout(value.data_ptr(), vt.data_ptr(), None, n, s, m, d, dv, 1, st)
 nb = lib.msda_backward_workspace_bytes(n, s, m, d, lq, l, p, dv, dl, 8, host)
-ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
+ws = torch.zeros(nb, dtype=torch.uint8, device="cuda")  # ablation builds leave records unwritten: zeros are valid records
 for _ in range(3):
     rc = lib.msda_backward(g.data_ptr(), vt.data_ptr(), shapes.data_ptr(), lsi.data_ptr(), loc.data_ptr(), attn.data_ptr(), None, gv.data_ptr(), gl.data_ptr(), ga.data_ptr(), ws.data_ptr(), nb, n, s, m, d, lq, l, p, dv, dl, 8, host, st); assert rc == 0
 torch.cuda.synchronize()
 import numpy as np
 G = 1 << 15
 buf = (ctypes.c_ulonglong * (G * 16))()
-names = [["levels+tilemap", "issue point loads", "zero counters", "count (waits loads)", "scan+dir row", "stage+emit own", "barrier after stage", "go row load+copy", "gather+dots+stores", "barrier after gather"],
+names = [["levels+tilemap", "issue point loads", "zero counters", "count (waits loads)", "scan+dir row", "park + stage first chunk (after emit)", "barrier after stage", "go row load+copy", "gather+dots+stores", "barrier after gather", "emit: records into the LDS image", "emit: barrier", "emit: linear copy + barrier"],
          ["setup: dir column + run scan", "A records+count own", "barrier A", "B scan", "C fill own", "barrier C", "D walk own", "barrier D"]]
 for which, kname in ((0, "bwd_query_kernel"), (1, "bwd_tile_gather_kernel")):
     lib.msda_debug_read_stamps.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_int]

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-2 evidence: one tools/collect_profiles.sh run per tag (set $1 = a or b for the two halves).
+# Evidence for every benchmark configuration: one tools/collect_profiles.sh run per tag (set $1 = a or b for the two halves).
 cd "$GRAFT_REPO_ROOT" || exit 1
 if [ "$1" = a ]; then
   bash tools/collect_profiles.sh r02_cityscapes_fp32_b8 &&

@@ -1281,7 +1281,9 @@ __global__ __launch_bounds__(256) void bwd_tile_gather_kernel(
       const uint32_t i = base + j * 256 + threadIdx.x;
       rloc[j] = 0xffffffffu;
       rq[j] = 0;
-      if (i < total && !(kAblate & 32)) {
+      // (a query index outside the tensor can only come from a corrupted record: dropped, so
+      // that no row address is ever formed from it)
+      if (i < total && (recs[j].x & 0x0fffffffu) < static_cast<uint32_t>(Lq) && !(kAblate & 32)) {
         const uint4 rec = recs[j];
         const int l = static_cast<int>(rec.x >> 28);
         const LevelInfo L_ = lv[l];
