@@ -761,6 +761,7 @@ __global__ __launch_bounds__(256, MSDA_K3_MINWAVES) void bwd_query_kernel(
   // 256 * j, i.e. point `i` (level `l`) of query `q` of the chunk — the same for every chunk;
   // px / py / pa hold location and weight of point j of chunk c at [c * KPC + j].
   float px[PRE], py[PRE], pa[PRE];
+  uint32_t pdesc[PRE];  // per point: record mask and destination tiles, count pass -> emit pass
   const float inv_LP = 1.0f / static_cast<float>(LP), inv_P = 1.0f / static_cast<float>(P);
   const auto point_of = [&](int j, int& q, int& i, int& l) {
     int p_unused;
@@ -805,14 +806,24 @@ __global__ __launch_bounds__(256, MSDA_K3_MINWAVES) void bwd_query_kernel(
         point_of(k % KPC, q, i, l);
         const LevelInfo L_ = lv[l];
         const Footprint<float> f = footprint<float>(px[k], py[k], L_.H, L_.W);
+        uint32_t desc = 0;
         if (f.any && pa[k] != 0.f) {
           uint32_t tiles[4];
           bool keep[4];
           footprint_tiles(f, plan, tm, L_, l, tiles, keep);
 #pragma unroll
           for (int j = 0; j < 4; ++j)
-            if (keep[j]) atomicAdd(&tile_cnt[tiles[j]], 1u);
+            if (keep[j]) {
+              atomicAdd(&tile_cnt[tiles[j]], 1u);
+              desc |= 1u << j;
+            }
+          // what the emit pass needs of this footprint: which corners send a record, and their
+          // tiles — corner 1 / 3 sits in the tile of corner 0 / 2 or in the next one (tile
+          // indices are below 4096)
+          desc |= (tiles[0] & 0xfffu) << 4 | (tiles[2] & 0xfffu) << 16 |
+                  ((tiles[1] - tiles[0]) & 1u) << 28 | ((tiles[3] - tiles[2]) & 1u) << 29;
         }
+        pdesc[k] = desc;
       }
     } else {
       const int npts = qb_n * LP;
@@ -869,11 +880,29 @@ __global__ __launch_bounds__(256, MSDA_K3_MINWAVES) void bwd_query_kernel(
       // image (uniformly scattered locations produce more) are stored directly.
 #pragma unroll
       for (int k = 0; k < PRE; ++k) {
-        int q, i, l;
-        point_of(k % KPC, q, i, l);
-        const LevelInfo L_ = lv[l];
-        const Footprint<float> f = footprint<float>(px[k], py[k], L_.H, L_.W);
-        emit_records(f, L_, l, px[k], py[k], pa[k], qb0 + (k / KPC) * GPB + q, emit);
+        const uint32_t desc = pdesc[k];  // from the count pass: no second footprint
+        if (desc & 15u) {
+          int q, i, l;
+          point_of(k % KPC, q, i, l);
+          const uint32_t t0 = (desc >> 4) & 0xfffu, t2 = (desc >> 16) & 0xfffu;
+          const uint32_t tiles[4] = {t0, t0 + ((desc >> 28) & 1u), t2, t2 + ((desc >> 29) & 1u)};
+          uint4 rec;
+          rec.x = static_cast<uint32_t>(qb0 + (k / KPC) * GPB + q) | (static_cast<uint32_t>(l) << 28);
+          rec.y = __float_as_uint(pa[k]);
+          rec.z = __float_as_uint(px[k]);
+          rec.w = __float_as_uint(py[k]);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            if ((desc >> j) & 1u) {
+              const uint32_t at = tile_off[tiles[j]] + atomicAdd(&tile_cnt[tiles[j]], 1u);
+              if (at < emit.lds_cap) {
+                emit.lds_image[at] = rec;  // leaves the workgroup later, as part of one linear copy
+              } else if (at < plan.region) {  // always true: a bug stays in the region
+                emit.records[at] = rec;
+              }
+            }
+          }
+        }
       }
       if (emit.lds_cap > 0) {
         __syncthreads();
