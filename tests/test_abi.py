@@ -246,3 +246,14 @@ def test_point_sample_argument_errors():
     assert ws(200, 1, 256, 512, 12544, _lib.BF16) == 0  # the backward takes fp32 / fp64
     assert ws(1, 2, 3, 9000, 700, _lib.F32) == 0  # too wide for LDS bands: atomic path, no lists
     assert ws(0, 1, 2, 2, 3, _lib.F32) == 0
+
+
+def test_tuned_kernels_refuse_what_their_24_bit_offsets_cannot_hold():
+    """The tuned kernels form pixel, row and query offsets with 24-bit multiplies: 2^24 queries
+    (or positions) are left to the generic kernels, which the support query reports."""
+    lib = _lib.load()
+    hm = lib.msda_head_major_supported
+    assert hm(1, 1 << 18, 8, 32, 1 << 18, 3, 4, _lib.F32, _lib.F32) == 1
+    assert hm(1, 1024, 1, 32, (1 << 18) - 1, 1, 4, _lib.BF16, _lib.BF16) == 1
+    assert hm(1, 1024, 1, 32, 1 << 24, 1, 4, _lib.BF16, _lib.BF16) == 0
+    assert hm(1, 1 << 24, 1, 32, 1024, 1, 4, _lib.BF16, _lib.BF16) == 0

@@ -73,7 +73,9 @@ struct Footprint {
   bool any;     // false when the point lies outside the (-1, H) x (-1, W) skirt: contributes nothing
 };
 
-template <typename CT>
+// SMALL: H * W fits 24 bits (the caller's promise), so the row offsets come from the full-rate
+// 24-bit multiply instead of the quarter-rate 32-bit one.
+template <typename CT, bool SMALL = false>
 __device__ __forceinline__ Footprint<CT> footprint(CT locx, CT locy, int H, int W) {
   Footprint<CT> f;
   const CT x = locx * static_cast<CT>(W) - static_cast<CT>(0.5);
@@ -105,10 +107,12 @@ __device__ __forceinline__ Footprint<CT> footprint(CT locx, CT locy, int H, int 
   f.cy[1] = yc1;
   f.cx[0] = xc0;
   f.cx[1] = xc1;
-  f.pix[0] = yc0 * W + xc0;
-  f.pix[1] = yc0 * W + xc1;
-  f.pix[2] = yc1 * W + xc0;
-  f.pix[3] = yc1 * W + xc1;
+  const int r0 = SMALL ? static_cast<int>(__umul24(yc0, W)) : yc0 * W;  // (both non-negative)
+  const int r1 = SMALL ? static_cast<int>(__umul24(yc1, W)) : yc1 * W;
+  f.pix[0] = r0 + xc0;
+  f.pix[1] = r0 + xc1;
+  f.pix[2] = r1 + xc0;
+  f.pix[3] = r1 + xc1;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     f.valid[k] = v[k];

@@ -293,11 +293,11 @@ __device__ __forceinline__ void pixel_tile(const BinPlan& plan, const TileMap& t
                                            uint32_t& tile, uint32_t& local) {
   if (plan.tile2d) {
     const int tw_shift = plan.tw_shift, th_shift = plan.ts_shift - plan.tw_shift;
-    tile = static_cast<uint32_t>(tm.tstart[l] + (cy >> th_shift) * tm.tx[l] + (cx >> tw_shift));
+    tile = static_cast<uint32_t>(tm.tstart[l] + __umul24(cy >> th_shift, tm.tx[l]) + (cx >> tw_shift));
     local = static_cast<uint32_t>(((cy & ((1 << th_shift) - 1)) << tw_shift) |
                                   (cx & ((1 << tw_shift) - 1)));
   } else {
-    const uint32_t pos = static_cast<uint32_t>(L_.start + cy * L_.W + cx);
+    const uint32_t pos = static_cast<uint32_t>(L_.start + __umul24(cy, L_.W) + cx);
     tile = pos >> plan.ts_shift;
     local = pos & ((1u << plan.ts_shift) - 1u);
   }
@@ -318,8 +318,8 @@ __device__ __forceinline__ void footprint_tiles(const Footprint<float>& f, const
     const int ty0 = f.cy[0] >> th_shift, ty1 = f.cy[1] >> th_shift;
     const int tx0 = f.cx[0] >> tw_shift, tx1 = f.cx[1] >> tw_shift;
     const int txl = tm.tx[l];
-    const uint32_t base0 = static_cast<uint32_t>(tm.tstart[l] + ty0 * txl);
-    const uint32_t base1 = static_cast<uint32_t>(tm.tstart[l] + ty1 * txl);
+    const uint32_t base0 = static_cast<uint32_t>(tm.tstart[l] + __umul24(ty0, txl));
+    const uint32_t base1 = static_cast<uint32_t>(tm.tstart[l] + __umul24(ty1, txl));
     const bool r0 = f.vy[0], r1 = f.vy[1] && !(f.vy[0] && ty1 == ty0);
     const bool c0 = f.vx[0], c1 = f.vx[1] && !(f.vx[0] && tx1 == tx0);
     t[0] = base0 + tx0;
@@ -349,7 +349,7 @@ __device__ __forceinline__ void footprint_tiles(const Footprint<float>& f, const
 // instruction sequence: a float estimate, corrected by at most one step.  `inv` = 1.0f / d.
 __device__ __forceinline__ void small_divmod(int t, int d, float inv, int& q, int& r) {
   q = static_cast<int>((static_cast<float>(t) + 0.5f) * inv);
-  r = t - q * d;
+  r = t - __mul24(q, d);  // (both far below 2^23)
   if (r < 0) {
     --q;
     r += d;
@@ -368,12 +368,15 @@ struct PointRows {
   int loc, attn;
 };
 
-// sampling location (x, y) and attention weight of point i of row `row`
+// sampling location (x, y) and attention weight of point i of a row of the workgroup:
+// `loc_wg` / `attn_wg` point at the first row the
+// workgroup touches (a uniform 64-bit address), `row` counts rows from there, and the element
+// offset comes from 24-bit multiplies (rows per workgroup and row lengths are small).
 template <typename LT>
-__device__ __forceinline__ void load_point(const LT* __restrict__ loc, const LT* __restrict__ attn,
-                                           int64_t row, int i, PointRows rs, float& x, float& y,
-                                           float& a) {
-  const LT* xy_p = loc + row * rs.loc + 2 * i;
+__device__ __forceinline__ void load_point_near(const LT* __restrict__ loc_wg,
+                                                const LT* __restrict__ attn_wg, uint32_t row, int i,
+                                                PointRows rs, float& x, float& y, float& a) {
+  const LT* xy_p = loc_wg + (__umul24(row, static_cast<uint32_t>(rs.loc)) + 2u * i);
   if constexpr (sizeof(LT) == 4) {
     const float2 xy = *reinterpret_cast<const float2*>(xy_p);
     x = xy.x;
@@ -384,7 +387,7 @@ __device__ __forceinline__ void load_point(const LT* __restrict__ loc, const LT*
     x = Elem<LT>::load(&pair[0]);
     y = Elem<LT>::load(&pair[1]);
   }
-  a = Elem<LT>::load(attn + row * rs.attn + i);
+  a = Elem<LT>::load(attn_wg + (__umul24(row, static_cast<uint32_t>(rs.attn)) + i));
 }
 
 struct EmitCtx {
@@ -461,16 +464,16 @@ __device__ __forceinline__ void stage_point(const LevelInfo& L_, int l, float x,
                                             int q, uint4* dst, uint32_t rowb, uint32_t headb,
                                             const EmitCtx& emit, bool raw = false) {
   constexpr int SLOTS = stage_slots(KIND);
-  const Footprint<float> f = footprint<float>(x, y, L_.H, L_.W);
+  const Footprint<float> f = footprint<float, true>(x, y, L_.H, L_.W);
   uint4 wrec, orec;
   wrec.x = __float_as_uint(a * f.w[0]);
   wrec.y = __float_as_uint(a * f.w[1]);
   wrec.z = __float_as_uint(a * f.w[2]);
   wrec.w = __float_as_uint(a * f.w[3]);
-  orec.x = (static_cast<uint32_t>(L_.start + f.pix[0]) * rowb + headb) | (f.valid[0] ? 1u : 0u);
-  orec.y = (static_cast<uint32_t>(L_.start + f.pix[1]) * rowb + headb) | (f.valid[1] ? 1u : 0u);
-  orec.z = (static_cast<uint32_t>(L_.start + f.pix[2]) * rowb + headb) | (f.valid[2] ? 1u : 0u);
-  orec.w = (static_cast<uint32_t>(L_.start + f.pix[3]) * rowb + headb) | (f.valid[3] ? 1u : 0u);
+  orec.x = (__umul24(static_cast<uint32_t>(L_.start + f.pix[0]), rowb) + headb) | (f.valid[0] ? 1u : 0u);
+  orec.y = (__umul24(static_cast<uint32_t>(L_.start + f.pix[1]), rowb) + headb) | (f.valid[1] ? 1u : 0u);
+  orec.z = (__umul24(static_cast<uint32_t>(L_.start + f.pix[2]), rowb) + headb) | (f.valid[2] ? 1u : 0u);
+  orec.w = (__umul24(static_cast<uint32_t>(L_.start + f.pix[3]), rowb) + headb) | (f.valid[3] ? 1u : 0u);
   if constexpr (KIND != kStageBwdBinned) dst[0] = wrec;
   dst[KIND == kStageBwdBinned ? 0 : 1] = orec;
   if constexpr (KIND != kStageFwd) {
@@ -500,18 +503,20 @@ __device__ __forceinline__ void stage_chunk(const LevelInfo* lv, const LT* __res
   const int npts = nq * nI;
   const int stride = group_stride_slots(LPB, SLOTS);
   const float inv_nI = 1.0f / static_cast<float>(nI), inv_P = 1.0f / static_cast<float>(P);
+  const int64_t row0 = (static_cast<int64_t>(b) * Lq + q_first) * M + m;  // first query's row
+  const LT* loc_wg = loc + row0 * rs.loc;
+  const LT* attn_wg = attn + row0 * rs.attn;
+  const float* ref_wg = ref == nullptr ? nullptr : ref + (static_cast<int64_t>(b) * Lq + q_first) * L * 2;
   for (int t = threadIdx.x; t < npts; t += 256) {
     int g, ii, l, p_unused;
     small_divmod(t, nI, inv_nI, g, ii);
     const int i = i_first + ii;
     small_divmod(i, P, inv_P, l, p_unused);
-    const int64_t row = (static_cast<int64_t>(b) * Lq + q_first + g) * M + m;
     float x, y, a;
-    load_point(loc, attn, row, i, rs, x, y, a);
+    load_point_near(loc_wg, attn_wg, __umul24(g, M), i, rs, x, y, a);
     if (ref != nullptr)
-      raw_to_point(ref + ((static_cast<int64_t>(b) * Lq + q_first + g) * L + l) * 2, lv[l],
-                   row_stats[g], x, y, a);
-    stage_point<KIND, EMIT>(lv[l], l, x, y, a, q_first + g, stage + g * stride + SLOTS * ii, rowb,
+      raw_to_point(ref_wg + (__umul24(g, L) + l) * 2u, lv[l], row_stats[g], x, y, a);
+    stage_point<KIND, EMIT>(lv[l], l, x, y, a, q_first + g, stage + (__umul24(g, stride) + SLOTS * ii), rowb,
                             headb, emit, ref != nullptr);
   }
 }
@@ -570,7 +575,7 @@ __global__ __launch_bounds__(256) void fwd_tuned_kernel(
   const char* vb = reinterpret_cast<const char*>(value) +
                    static_cast<int64_t>(b) * S * M * D * static_cast<int64_t>(sizeof(VT));
   const uint32_t lane_b = lane * 16;
-  const uint4* rec = lds + g * group_stride_slots(LPB, 2);
+  const uint4* rec = lds + __umul24(g, group_stride_slots(LPB, 2));
 
   float acc[NC][CPL];
 #pragma unroll
@@ -771,6 +776,11 @@ __global__ __launch_bounds__(256, MSDA_K3_MINWAVES) void bwd_query_kernel(
   // pending chunks' points, parked in LDS while a chunk is gathered: [(c - 1) * KPC + j][x, y, a][thread]
   float* stash = reinterpret_cast<float*>(stage + stage_total);
   if constexpr (KPC > 0) {
+    // rows of this workgroup: uniform 64-bit bases, small per-point offsets
+    const int64_t row0 = (static_cast<int64_t>(b) * Lq + qb0) * M + m;
+    const LT* loc_wg = loc + row0 * rs.loc;
+    const LT* attn_wg = attn + row0 * rs.attn;
+    const float* ref_wg = raw ? ref + (static_cast<int64_t>(b) * Lq + qb0) * L * 2 : nullptr;
 #pragma unroll
     for (int c = 0; c < NCHUNK; ++c)
 #pragma unroll
@@ -781,12 +791,10 @@ __global__ __launch_bounds__(256, MSDA_K3_MINWAVES) void bwd_query_kernel(
         point_of(j, q, i, l);
         const int qi = c * GPB + q;
         const bool have = q < GPB && qi < qb_n;
-        const int64_t row = (static_cast<int64_t>(b) * Lq + qb0 + (have ? qi : 0)) * M + m;
+        const uint32_t qc = have ? qi : 0;
         float x, y, a;
-        load_point(loc, attn, row, i, rs, x, y, a);
-        if (raw)
-          raw_to_point(ref + ((static_cast<int64_t>(b) * Lq + qb0 + (have ? qi : 0)) * L + l) * 2,
-                       lv[l], row_stats[have ? qi : 0], x, y, a);
+        load_point_near(loc_wg, attn_wg, __umul24(qc, M), i, rs, x, y, a);
+        if (raw) raw_to_point(ref_wg + (__umul24(qc, L) + l) * 2u, lv[l], row_stats[qc], x, y, a);
         px[c * KPC + j] = have ? x : -4.f;  // outside every level: no footprint
         py[c * KPC + j] = have ? y : -4.f;
         pa[c * KPC + j] = have ? a : 0.f;
@@ -805,7 +813,7 @@ __global__ __launch_bounds__(256, MSDA_K3_MINWAVES) void bwd_query_kernel(
         int q, i, l;
         point_of(k % KPC, q, i, l);
         const LevelInfo L_ = lv[l];
-        const Footprint<float> f = footprint<float>(px[k], py[k], L_.H, L_.W);
+        const Footprint<float> f = footprint<float, true>(px[k], py[k], L_.H, L_.W);
         uint32_t desc = 0;
         if (f.any && pa[k] != 0.f) {
           uint32_t tiles[4];
@@ -828,15 +836,17 @@ __global__ __launch_bounds__(256, MSDA_K3_MINWAVES) void bwd_query_kernel(
     } else {
       const int npts = qb_n * LP;
       const float inv_LP = 1.0f / static_cast<float>(LP), inv_P = 1.0f / static_cast<float>(P);
+      const int64_t row0 = (static_cast<int64_t>(b) * Lq + qb0) * M + m;
+      const LT* loc_wg = loc + row0 * rs.loc;
+      const LT* attn_wg = attn + row0 * rs.attn;
       for (int t = threadIdx.x; t < npts; t += 256) {
         int g, i, l, p_unused;
         small_divmod(t, LP, inv_LP, g, i);
         small_divmod(i, P, inv_P, l, p_unused);
         const LevelInfo L_ = lv[l];
-        const int64_t row = (static_cast<int64_t>(b) * Lq + qb0 + g) * M + m;
         float x, y, a;
-        load_point(loc, attn, row, i, rs, x, y, a);
-        const Footprint<float> f = footprint<float>(x, y, L_.H, L_.W);
+        load_point_near(loc_wg, attn_wg, __umul24(g, M), i, rs, x, y, a);
+        const Footprint<float> f = footprint<float, true>(x, y, L_.H, L_.W);
         if (f.any && a != 0.f) {
           uint32_t tiles[4];
           bool keep[4];
@@ -926,7 +936,7 @@ __global__ __launch_bounds__(256, MSDA_K3_MINWAVES) void bwd_query_kernel(
         point_of(j, q, i, l);
         if (q < nq0)
           stage_point<KIND, false>(lv[l], l, px[j], py[j], pa[j], qb0 + q,
-                                   stage + q * stride + SL * i, rowb, headb, emit, raw);
+                                   stage + (__umul24(q, stride) + SL * i), rowb, headb, emit, raw);
       }
     }
   }
@@ -954,7 +964,7 @@ __global__ __launch_bounds__(256, MSDA_K3_MINWAVES) void bwd_query_kernel(
     // lanes of groups past the end redo the last group (no writes) so that every DPP row is full
     const bool live = g < nq;
     const int gg = live ? g : nq - 1;
-    const uint4* r = stage + gg * group_stride_slots(LPB, SL);
+    const uint4* r = stage + __umul24(gg, group_stride_slots(LPB, SL));
     const int64_t triple = (static_cast<int64_t>(b) * Lq + qb0 + c0 + gg) * M + m;
     float go[NC][CPL];
     uint4 go_raw[NC];  // the same chunks as loaded (16-bit types: still packed)
@@ -1191,7 +1201,7 @@ __global__ __launch_bounds__(256, MSDA_K3_MINWAVES) void bwd_query_kernel(
           const float a = stash[(((cn - 1) * KPC + j) * 3 + 2) * 256 + threadIdx.x];
           if (q < nqn)
             stage_point<KIND, false>(lv[l], l, x, y, a, qb0 + cn * GPB + q,
-                                     stage + q * stride + SL * i, rowb, headb, emit, raw);
+                                     stage + (__umul24(q, stride) + SL * i), rowb, headb, emit, raw);
         }
       }
     }
@@ -1274,7 +1284,9 @@ __global__ __launch_bounds__(256) void bwd_tile_gather_kernel(
                         (g_head_major ? slab * Lq : static_cast<int64_t>(b) * Lq * M + m) * ROWB;
   const uint32_t tile_u = static_cast<uint32_t>(tile);
   const int pg = threadIdx.x / PL, pl = threadIdx.x % PL;
-  const int64_t q_stride = static_cast<int64_t>(g_head_major ? 1 : M) * ROWB;
+  // bytes between the rows of consecutive queries; offsets inside a slab fit 32 bits and both
+  // factors 24 bits (tuned_shape_ok)
+  const uint32_t q_stride = static_cast<uint32_t>(g_head_major ? 1 : M) * ROWB;
 
   float sum[NCH][CPL];
 #pragma unroll
@@ -1318,7 +1330,7 @@ __global__ __launch_bounds__(256) void bwd_tile_gather_kernel(
         const LevelInfo L_ = lv[l];
         const float a = __uint_as_float(rec.y);
         const Footprint<float> f =
-            footprint<float>(__uint_as_float(rec.z), __uint_as_float(rec.w), L_.H, L_.W);
+            footprint<float, true>(__uint_as_float(rec.z), __uint_as_float(rec.w), L_.H, L_.W);
         rq[j] = rec.x & 0x0fffffffu;
         uint32_t packed = 0;
 #pragma unroll
@@ -1371,7 +1383,7 @@ __global__ __launch_bounds__(256) void bwd_tile_gather_kernel(
         for (int u = 0; u < U; ++u) {
           const uint2 ent = entries[min(e + u, e1 - 1)];
           w[u] = e + u < e1 ? __uint_as_float(ent.y) : 0.f;  // weight 0: a repeated row adds nothing
-          const char* row = go_slab + static_cast<int64_t>(ent.x) * q_stride + pl * 16;
+          const char* row = go_slab + (__umul24(ent.x, q_stride) + pl * 16u);
 #pragma unroll
           for (int j = 0; j < NCH; ++j) Chunk<VT>::load(row + j * PL * 16, rv[u][j]);
         }
@@ -1444,6 +1456,11 @@ inline bool tuned_shape_ok(int N, int S, int M, int D, int Lq, int L, int P, int
   if (L > kMaxLevelsTuned) return false;
   const int esize = cpl == 4 ? 4 : 2;
   if (static_cast<int64_t>(S) * M * D * esize > static_cast<int64_t>(UINT32_MAX)) return false;
+  // the kernels form pixel, row and query offsets with 24-bit multiplies and 32-bit sums
+  if (S >= (1 << 24) || Lq >= (1 << 24) || static_cast<int64_t>(M) * D * esize >= (1 << 24) ||
+      static_cast<int64_t>(M) * 3 * L * P >= (1 << 24) ||
+      static_cast<int64_t>(Lq) * M * D * esize > static_cast<int64_t>(UINT32_MAX))
+    return false;
   if (N > 65535) return false;
   const int GPB = 256 / (2 * G);  // fewest queries per workgroup of any kernel
   if ((static_cast<int64_t>(Lq) + GPB - 1) / GPB * M > INT32_MAX) return false;
