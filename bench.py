@@ -482,7 +482,7 @@ def main() -> None:
             "data": "synthetic",
             "config": {
                 "workload": w.name,
-                "entry_point": "MSDeformAttn layer (projections on PyTorch-ROCm GEMMs + point epilogue + packed-points kernels)"
+                "entry_point": "MSDeformAttn layer (projections on PyTorch-ROCm GEMMs, per-head value epilogue, raw-points attention kernels)"
                 if args.layer
                 else "MultiScaleFlashAttnFunction kernels (packed locations+weights, read in place)"
                 if args.packed
