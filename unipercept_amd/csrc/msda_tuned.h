@@ -706,7 +706,7 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t* data, int n, 
 // registers: the tensors are read once instead of twice, and the nine dependent global round
 // trips per thread of the count pass plus three per staging pass (each waits behind the gathers
 // of the other workgroups of the CU) become one.
-template <typename VT, typename LT, int G, int MODE, int KPC = 0>
+template <typename VT, typename LT, int G, int MODE, int KPC = 0, int QB = 192>
 __global__ __launch_bounds__(256, MSDA_K3_MINWAVES) void bwd_query_kernel(
     const VT* __restrict__ grad_out, const VT* __restrict__ value,
     const int64_t* __restrict__ shapes, const int64_t* __restrict__ lsi,
@@ -721,7 +721,7 @@ __global__ __launch_bounds__(256, MSDA_K3_MINWAVES) void bwd_query_kernel(
   constexpr int GPB = 256 / GQ;
   constexpr int KIND = MODE == 1 ? kStageBwdBinned : kStageBwdAtomic;
   constexpr int SL = stage_slots(KIND);
-  constexpr int NCHUNK = 192 / GPB;                    // KPC > 0: chunks of GPB queries per workgroup
+  constexpr int NCHUNK = QB / GPB;                         // KPC > 0: chunks of GPB queries per workgroup
   constexpr int PRE = KPC > 0 ? NCHUNK * KPC : 1;      // points a thread keeps in registers
   static_assert(KPC == 0 || MODE == 1, "register-resident points: binned mode only");
   extern __shared__ uint4 lds[];
@@ -737,7 +737,7 @@ __global__ __launch_bounds__(256, MSDA_K3_MINWAVES) void bwd_query_kernel(
   const int qb_n = min(plan.qb, Lq - qb0);
   MSDA_STAMP_DECL;
   // raw points (KPC > 0 only; the host refuses them elsewhere): softmax statistics of the rows
-  __shared__ float2 row_stats[KPC > 0 ? 192 : 1];
+  __shared__ float2 row_stats[KPC > 0 ? QB : 1];
   const bool raw = KPC > 0 && ref != nullptr;
   if (threadIdx.x < L) lv[threadIdx.x] = load_level(shapes, lsi, threadIdx.x, S);
   if constexpr (KPC > 0) {
@@ -1497,24 +1497,35 @@ inline bool all_aligned16(std::initializer_list<const void*> ps) {
 // (L pairs (H, W), host memory, may be null) selects the 2-D tile geometry when the level table
 // is a plain pyramid (positive extents that sum to S) and its tile count is within the limits;
 // otherwise tiles are runs of the flattened sequence.
-inline bool make_bin_plan(int N, int S, int M, int D, int Lq, int L, int P,
+// Queries per query-side workgroup: 192 (three passes of 64 at 4 lanes per query) measured 2 %
+// faster than 256 on the Cityscapes shapes (14336 workgroups fill the chip's 1024 resident ones
+// 14 times exactly; 128 and 320 sit between, 64 and 512 are slower than 256).  The
+// register-resident form of the query kernel parks the points of all but the first pass in LDS;
+// when that leaves room for only two workgroups per CU (16 points per query: 61 KB) and 128
+// queries per workgroup make it three, 128 it is (COCO 4 levels x 4 points, bf16: backward
+// 2.44 -> 2.27 ms; with 12 points per query both sizes run three workgroups and 128 is 2 %
+// slower).  G = 16-byte chunks per row, 0 when not known.
+inline int choose_qb(int G, int LP, int64_t n_tiles) {
+  if (!MSDA_K3_PRE || G == 0 || LP > 16) return 192;
+  const int GQ = query_lanes(G), GPB = 256 / GQ;
+  const int kpc = GQ == 4 ? (LP <= 12 ? 3 : 4) : 2;
+  const auto resident = [&](int qb) {
+    const int64_t lds = static_cast<int64_t>(GPB) * group_stride_slots(LP, stage_slots(kStageBwdBinned)) * 16 +
+                        (2 * n_tiles + 3) / 4 * 16 + static_cast<int64_t>(qb / GPB - 1) * kpc * 3 * 1024;
+    return (160 * 1024) / (lds + 4096);  // (+ static arrays and allocation granularity)
+  };
+  return resident(192) < 3 && resident(128) > resident(192) ? 128 : 192;
+}
+
+inline bool make_bin_plan(int N, int S, int M, int D, int Lq, int L, int P, int G,
                           const int64_t* levels_host, BinPlan* plan, size_t* dir_bytes,
                           size_t* rec_bytes) {
   if (D > 64) return false;                  // accumulators of a position: D / 4 registers per lane
   const int ts_shift = kTileShift, tw_shift = kTileWidthShift;
   const int TS = 1 << ts_shift;
-  // queries per query-side workgroup: three passes of 64.  192 measured 2 % faster than 256 on
-  // the Cityscapes shapes (14336 workgroups fill the chip's 1024 resident ones 14 times exactly;
-  // 128 and 320 sit between, 64 and 512 are slower than 256)
-  const int qb = 192;
-  const int64_t n_qblocks = (static_cast<int64_t>(Lq) + qb - 1) / qb;
   const int64_t slabs = static_cast<int64_t>(N) * M;
-  const auto fits = [&](int64_t nt) {
-    return nt <= 4096 && slabs * n_qblocks * nt * 8 <= (static_cast<int64_t>(1) << 30) &&
-           nt * M <= INT32_MAX;
-  };
   int64_t n_tiles = (static_cast<int64_t>(S) + TS - 1) / TS;
-  int tile2d = 0;
+  int64_t nt2d = -1;  // tile count of the 2-D geometry when the level table allows it
   if (levels_host != nullptr) {
     const int tw = 1 << tw_shift, th = TS >> tw_shift;
     int64_t total = 0, nt = 0;
@@ -1526,10 +1537,18 @@ inline bool make_bin_plan(int N, int S, int M, int D, int Lq, int L, int P,
       nt += ((h + th - 1) / th) * ((w + tw - 1) / tw);
       if (total > S) { ok = false; break; }
     }
-    if (ok && total == S && fits(nt)) {
-      n_tiles = nt;
-      tile2d = 1;
-    }
+    if (ok && total == S) nt2d = nt;
+  }
+  const int qb = choose_qb(G, L * P, nt2d >= 0 ? nt2d : n_tiles);
+  const int64_t n_qblocks = (static_cast<int64_t>(Lq) + qb - 1) / qb;
+  const auto fits = [&](int64_t nt) {
+    return nt <= 4096 && slabs * n_qblocks * nt * 8 <= (static_cast<int64_t>(1) << 30) &&
+           nt * M <= INT32_MAX;
+  };
+  int tile2d = 0;
+  if (nt2d >= 0 && fits(nt2d)) {
+    n_tiles = nt2d;
+    tile2d = 1;
   }
   if (!fits(n_tiles) || n_qblocks > 2048 || Lq >= (1 << 28)) return false;
   const int64_t dir_b = slabs * n_qblocks * n_tiles * 8;
@@ -1558,7 +1577,7 @@ inline bool head_major_supported(int N, int S, int M, int D, int Lq, int L, int 
   BinPlan plan;
   size_t a, b;
   return tuned_shape_ok(N, S, M, D, Lq, L, P, dtype_val, dtype_loc, &G) &&
-         make_bin_plan(N, S, M, D, Lq, L, P, nullptr, &plan, &a, &b);
+         make_bin_plan(N, S, M, D, Lq, L, P, G, nullptr, &plan, &a, &b);
 }
 
 // Whether forward and backward take raw points (offsets + logits + reference points): tuned
@@ -1570,8 +1589,8 @@ inline bool raw_points_supported(int N, int S, int M, int D, int Lq, int L, int 
   size_t a, b;
   return MSDA_K3_PRE && MSDA_K3_DEPTH == 2 &&
          tuned_shape_ok(N, S, M, D, Lq, L, P, dtype_val, dtype_loc, &G) && packed_shape_ok(L, P) &&
-         L * P <= 16 && make_bin_plan(N, S, M, D, Lq, L, P, nullptr, &plan, &a, &b) &&
-         plan.qb == 192;
+         L * P <= 16 && make_bin_plan(N, S, M, D, Lq, L, P, G, nullptr, &plan, &a, &b) &&
+         (plan.qb == 192 || plan.qb == 128);
 }
 
 // (N,S,M,D) <-> (N,M,S,D): rows of D*e bytes move whole, 16 bytes per lane.  `mask` (n, S) bytes,
@@ -1663,7 +1682,7 @@ inline int64_t tuned_backward_workspace_bytes(int N, int S, int M, int D, int Lq
   if (!tuned_shape_ok(N, S, M, D, Lq, L, P, dtype_val, dtype_loc, &G)) return -1;
   BinPlan plan;
   size_t dir_b, rec_b;
-  if (allow_binned && make_bin_plan(N, S, M, D, Lq, L, P, levels_host, &plan, &dir_b, &rec_b))
+  if (allow_binned && make_bin_plan(N, S, M, D, Lq, L, P, G, levels_host, &plan, &dir_b, &rec_b))
     return static_cast<int64_t>(dir_b + rec_b + g_copy_bytes(N, M, D, Lq, dtype_val));
   if (dtype_val == 0) return 0;
   return static_cast<int64_t>(N) * S * M * D * 4;  // fp32 accumulation image of grad_value
@@ -1687,13 +1706,13 @@ int tuned_backward_typed(const void* grad_out, const void* value, const int64_t*
   BinPlan plan{};
   size_t dir_b = 0, rec_b = 0;
   const bool binned =
-      allow_binned && make_bin_plan(N, S, M, D, Lq, L, P, levels_host, &plan, &dir_b, &rec_b);
+      allow_binned && make_bin_plan(N, S, M, D, Lq, L, P, G, levels_host, &plan, &dir_b, &rec_b);
   const int slots = stage_slots(binned ? kStageBwdBinned : kStageBwdAtomic);
   int LPB = stage_points_per_pass(GQ, LP, slots);
   // Register-resident points (see bwd_query_kernel): 4 lanes per query, three chunks of 64
   // queries per workgroup, up to 16 points per query staged in one pass (34 KB of LDS at 16).
   int kpc = 0;
-  if (MSDA_K3_PRE && binned && plan.qb == 192 && LP <= 16) {
+  if (MSDA_K3_PRE && binned && (plan.qb == 192 || plan.qb == 128) && LP <= 16) {
     kpc = GQ == 4 ? (LP <= 12 ? 3 : 4) : 2;  // ceil(GPB * LP / 256), rounded up to a built variant
     LPB = LP;
   }
@@ -1709,7 +1728,7 @@ int tuned_backward_typed(const void* grad_out, const void* value, const int64_t*
     const dim3 qgrid(static_cast<unsigned>(plan.n_qblocks) * M, N);
     const size_t qlds = static_cast<size_t>(GPB) * group_stride_slots(LPB, slots) * 16 +
                         (static_cast<size_t>(2 * plan.n_tiles + 3) / 4) * 16 +
-                        (kpc ? static_cast<size_t>((192 / GPB - 1) * kpc) * 3 * 256 * 4 : 0);  // parked points
+                        (kpc ? static_cast<size_t>((plan.qb / GPB - 1) * kpc) * 3 * 256 * 4 : 0);  // parked points
     const dim3 tgrid(static_cast<unsigned>(plan.n_tiles) * M, N);
     const size_t TSz = static_cast<size_t>(1) << plan.ts_shift;
     // Rounds of 512 records (2 per thread) and 3 entries per walk step (2 for rows of 16 chunks):
@@ -1726,7 +1745,13 @@ int tuned_backward_typed(const void* grad_out, const void* value, const int64_t*
                      shapes, lsi, records, dir, static_cast<VT*>(grad_value), S, M, Lq, L, plan, \
                      g_copy ? 1 : 0)
 #define MSDA_TQ(GG, KK)                                                                          \
-  hipLaunchKernelGGL((bwd_query_kernel<VT, LT, GG, 1, KK>), qgrid, dim3(256), qlds, stream,      \
+  if ((KK) > 0 && plan.qb == 128) {                                                              \
+    MSDA_TQB(GG, KK, ((KK) > 0 ? 128 : 192));                                                    \
+  } else {                                                                                       \
+    MSDA_TQB(GG, KK, 192);                                                                       \
+  }
+#define MSDA_TQB(GG, KK, QQ)                                                                     \
+  hipLaunchKernelGGL((bwd_query_kernel<VT, LT, GG, 1, KK, QQ>), qgrid, dim3(256), qlds, stream,  \
                      static_cast<const VT*>(grad_out), static_cast<const VT*>(value), shapes,    \
                      lsi, static_cast<const LT*>(loc), static_cast<const LT*>(attn),             \
                      static_cast<LT*>(grad_loc), static_cast<LT*>(grad_attn),                    \
@@ -1752,6 +1777,7 @@ int tuned_backward_typed(const void* grad_out, const void* value, const int64_t*
     }
 #undef MSDA_TB
 #undef MSDA_TQ
+#undef MSDA_TQB
 #undef MSDA_TILE
     e = hipGetLastError();
     return e == hipSuccess ? 0 : static_cast<int>(e);
