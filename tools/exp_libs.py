@@ -9,6 +9,9 @@ import ctypes, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from unipercept_amd import harness, _lib
 w = harness.WORKLOADS[os.environ.get("WORKLOAD", "cityscapes_1024x2048_fp32_b8")]
+if os.environ.get("HALF"):  # the same pyramid at half the resolution, four times the batch
+    import dataclasses
+    w = dataclasses.replace(w, levels=tuple((h // 2, ww // 2) for h, ww in w.levels), batch=4 * w.batch)
 value, shapes, lsi, loc, attn, g = harness.synth_inputs(w, "cuda", seed=1, dist=os.environ.get("DIST", "R"))
 def query_order(levels, spec):
     """QPERM=<th>x<tw>[c]: queries visited patch by patch (th x tw pixels of their own level,
