@@ -257,3 +257,29 @@ def test_tuned_kernels_refuse_what_their_24_bit_offsets_cannot_hold():
     assert hm(1, 1024, 1, 32, (1 << 18) - 1, 1, 4, _lib.BF16, _lib.BF16) == 1
     assert hm(1, 1024, 1, 32, 1 << 24, 1, 4, _lib.BF16, _lib.BF16) == 0
     assert hm(1, 1 << 24, 1, 32, 1024, 1, 4, _lib.BF16, _lib.BF16) == 0
+
+
+def test_workspace_reflects_queries_per_workgroup():
+    """Query blocks are 192 queries, or 128 where 16 points per query would otherwise leave room
+    for two workgroups per CU only; the workspace size is the visible side of that choice."""
+    lib = _lib.load()
+
+    def expect(n, m, d, esize, levels, p, qb):
+        s = sum(h * w for h, w in levels)
+        lq, l = s, len(levels)
+        tiles = sum(-(-h // 8) * -(-w // 8) for h, w in levels)
+        blocks = -(-lq // qb)
+        dir_b = (n * m * blocks * tiles * 8 + 255) // 256 * 256
+        rec_b = n * m * blocks * (qb * l * p * 4) * 16
+        return dir_b + rec_b + n * m * lq * d * esize
+
+    def got(n, m, d, dtype, levels, p):
+        s = sum(h * w for h, w in levels)
+        host = (ctypes.c_int64 * (2 * len(levels)))(*[x for hw in levels for x in hw])
+        return lib.msda_backward_workspace_bytes(n, s, m, d, s, len(levels), p, dtype, dtype, 0, host)
+
+    city = [(128, 256), (64, 128), (32, 64)]
+    coco = [(128, 128), (64, 64), (32, 32), (16, 16)]
+    assert got(8, 8, 32, _lib.F32, city, 4) == expect(8, 8, 32, 4, city, 4, 192)
+    assert got(8, 8, 32, _lib.BF16, city, 4) == expect(8, 8, 32, 2, city, 4, 192)
+    assert got(16, 8, 32, _lib.BF16, coco, 4) == expect(16, 8, 32, 2, coco, 4, 128)
