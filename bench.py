@@ -28,10 +28,33 @@ from pathlib import Path
 # RCCL over xGMI between the ranks of one node needs dmabuf IPC on this driver stack
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
-import torch  # noqa: E402
-
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
+
+
+def maybe_launch() -> None:
+    """The launcher branch, taken BEFORE torch (or anything else that could load the HIP runtime)
+    is imported: a plain `python bench.py --gpus N` (N > 1, or any N with --spawn) outside
+    torch.distributed.run starts N ranks of this script and exits with their status.  The parent
+    counts GPUs from sysfs only and never touches one."""
+    pre = argparse.ArgumentParser(add_help=False)
+    pre.add_argument("--gpus", type=int, default=1)
+    pre.add_argument("--spawn", action="store_true")
+    known, _ = pre.parse_known_args()
+    if "WORLD_SIZE" in os.environ or not (known.gpus > 1 or known.spawn):
+        return
+    from unipercept_amd import launch  # torch-free
+
+    visible = launch.visible_gpu_count()
+    if visible is not None and visible < known.gpus:
+        raise SystemExit(f"--gpus {known.gpus} but only {visible} GPU(s) are visible")
+    raise SystemExit(launch.launch_ranks(str(Path(__file__).resolve()), sys.argv[1:], known.gpus))
+
+
+if __name__ == "__main__":
+    maybe_launch()
+
+import torch  # noqa: E402
 
 from unipercept_amd import harness  # noqa: E402
 
@@ -281,6 +304,9 @@ def main() -> None:
                     "next step (overlap)")
     ap.add_argument("--no-head-major", action="store_true",
                     help="gather from the (N,S,M,D) value as given instead of a per-head copy")
+    ap.add_argument("--spawn", action="store_true",
+                    help="start the ranks from this script even for --gpus 1 (the self-launcher path "
+                    "of a plain `--gpus N` run, with the RCCL process group, rehearsed on one GPU)")
     args = ap.parse_args()
     _claim_stdout()
 
@@ -288,15 +314,7 @@ def main() -> None:
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if "WORLD_SIZE" not in os.environ and args.gpus > 1:
-            # invoked plainly: this process becomes the launcher (it has not touched the GPU and
-            # never will) and starts one rank per GPU; rank 0's JSON line goes to the inherited
-            # stdout
-            visible = torch.cuda.device_count()  # counting devices does not initialise the GPU
-            if visible < args.gpus:
-                raise SystemExit(f"--gpus {args.gpus} but only {visible} GPU(s) are visible")
-            os.dup2(_RESULT_OUT.fileno(), 1)  # the children inherit the real stdout
-            raise SystemExit(harness.launch_ranks(str(Path(__file__).resolve()), sys.argv[1:], args.gpus))
+        # (a plain `--gpus N` run never gets here: maybe_launch() turned it into N ranks)
         raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no GPU visible); there is no CPU fallback")

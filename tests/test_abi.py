@@ -117,8 +117,13 @@ def test_workspace_bytes():
     assert ws(1, 640, 2, 30, 2, 2, 2, _lib.F64, _lib.F64, 0) == 0
     # generic 16-bit path: fp32 image of grad_value
     assert ws(1, 640, 2, 30, 2, 2, 2, _lib.BF16, _lib.BF16, 0) == 640 * 2 * 30 * 4
-    # deterministic mode needs none
-    assert ws(1, 640, 2, 32, 2, 2, 2, _lib.BF16, _lib.BF16, _lib.FLAG_DETERMINISTIC) == 0
+    # reproducible mode: the binned path's scratch where the shape has one (also when the atomic
+    # scatter is asked for as well), none for the per-destination gather of the other shapes
+    det = _lib.FLAG_DETERMINISTIC
+    assert ws(1, 640, 2, 32, 2, 2, 2, _lib.BF16, _lib.BF16, det) == ws(1, 640, 2, 32, 2, 2, 2, _lib.BF16, _lib.BF16, 0) > 0
+    assert ws(1, 640, 2, 32, 2, 2, 2, _lib.BF16, _lib.BF16, det | _lib.FLAG_ATOMIC_SCATTER) == ws(1, 640, 2, 32, 2, 2, 2, _lib.BF16, _lib.BF16, 0)
+    assert ws(1, 640, 2, 30, 2, 2, 2, _lib.BF16, _lib.BF16, det) == 0
+    assert ws(1, 640, 2, 32, 2, 2, 2, _lib.F64, _lib.F64, det) == 0
     # binned path (Cityscapes shapes, batch 8): directory + 64 B per sampled point + grad_out copy
     n, s, m, d, l, p = 8, 43008, 8, 32, 3, 4
     tiles = -(-s // 64)  # 64 positions per destination tile

@@ -122,10 +122,73 @@ def test_launcher_spawns_one_rank_per_process(tmp_path):
 
 
 def test_bench_refuses_more_ranks_than_gpus():
-    """Without GPUs the plain `--gpus 2` invocation ends with a clear message (no launch)."""
+    """Without GPUs the plain `--gpus 2` invocation ends with a clear message: from the launcher
+    when sysfs shows fewer GPUs, else from the ranks it started (there is no CPU fallback)."""
     import subprocess
 
     if torch.cuda.device_count() >= 2:
         pytest.skip("two GPUs visible")
     r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=170)
-    assert r.returncode != 0 and "GPU(s) are visible" in r.stderr
+    assert r.returncode != 0
+    assert "GPU(s) are visible" in r.stderr or "no GPU visible" in r.stderr
+
+
+_LAUNCH_SPY = r"""
+import json, os, runpy, subprocess, sys
+seen = []
+class Spy:
+    def __init__(self, cmd, env=None, **kw):
+        # what the parent has loaded at the moment it starts a rank
+        seen.append({
+            "torch_loaded": any(m == "torch" or m.startswith("torch.") for m in sys.modules),
+            "ctypes_hip": any("amdhip" in (getattr(m, "__file__", "") or "") for m in list(sys.modules.values())),
+            "cmd": cmd[1:], "rank": env["RANK"], "world": env["WORLD_SIZE"],
+            "addr": env["MASTER_ADDR"], "ipc": env.get("HSA_ENABLE_IPC_MODE_LEGACY"),
+        })
+        self.returncode = 0
+    def poll(self): return 0
+    def wait(self, timeout=None): return 0
+    def terminate(self): pass
+    def kill(self): pass
+subprocess.Popen = Spy
+sys.argv = [sys.argv[1]] + sys.argv[2:]
+try:
+    runpy.run_path(sys.argv[0], run_name="__main__")
+except SystemExit as e:
+    print(json.dumps({"exit": e.code, "seen": seen}))
+"""
+
+
+@pytest.mark.parametrize("argv", [["--gpus", "2", "--steps", "3"], ["--gpus", "1", "--spawn"]])
+def test_launcher_parent_never_loads_torch(argv):
+    """The self-launcher of `python bench.py --gpus N` starts its ranks before torch (and with it
+    anything that could initialise the HIP runtime) has been imported into the parent; `--spawn`
+    takes the same path with one rank.  The ranks get the torch.distributed.run environment and
+    the launcher's own arguments."""
+    import json
+    import subprocess
+
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run(
+        [sys.executable, "-c", _LAUNCH_SPY, str(ROOT / "bench.py"), *argv],
+        capture_output=True, text=True, timeout=120, env=env,
+    )
+    assert r.returncode == 0, r.stderr[-2000:]
+    rec = json.loads(r.stdout.strip().splitlines()[-1])
+    n = int(argv[1])
+    assert rec["exit"] == 0 and len(rec["seen"]) == n
+    for rank, s in enumerate(rec["seen"]):
+        assert not s["torch_loaded"] and not s["ctypes_hip"]
+        assert s["cmd"] == [str(ROOT / "bench.py"), *argv]
+        assert (s["rank"], s["world"], s["addr"], s["ipc"]) == (str(rank), str(n), "127.0.0.1", "0")
+
+
+def test_visible_gpu_count_reads_no_runtime(monkeypatch):
+    from unipercept_amd import launch
+
+    got = launch.visible_gpu_count()
+    assert got is None or got >= 0
+    import glob as _glob
+
+    monkeypatch.setattr(_glob, "glob", lambda pattern: [])
+    assert launch.visible_gpu_count() is None

@@ -1,6 +1,6 @@
 """Full-size (benchmark shapes) checks: every benchmark shape family against the scalar C oracle
-on one whole sample (the oracle needs a few seconds per sample at these sizes), the batch-8
-headline launch against its own batch-1 slices and the oracle, and size-independent identities
+on one whole sample (the oracle needs a few seconds per sample at these sizes), the launches the
+benchmark times at their batch sizes against their own batch-1 slices and the oracle, and size-independent identities
 (adjoint, linearity, constant field) on top."""
 
 from __future__ import annotations
@@ -174,25 +174,38 @@ def test_full_size_sample_against_oracle(name, dist, scale):
     _check_against_oracle((out, v.grad, lo.grad, a.grad), want, "f32" if w.dtype == "f32" else "16", loc, w.levels)
 
 
-def test_headline_batch8_launch():
-    """The headline launch itself (batch 8, the index regime bench.py runs: 2.5 GB workspace,
-    blockIdx.y up to 7): adjoint identities over the whole batch, every sample equal to its own
-    batch-1 launch, and one sample of the batch against the oracle."""
+BENCH_BATCH = [
+    # workload at its bench batch size, sample checked against the oracle
+    ("cityscapes_1024x2048_fp32_b8", 5),  # the headline launch: 2.5 GB workspace
+    ("cityscapes_1024x2048_bf16_b8", 3),
+    ("coco_1024x1024_L4_bf16_b16", 11),   # 128-query blocks of the query kernel
+    ("dvps_1024x2048_L4_P8_fp32_b8", 6),  # 32 points per query
+]
+
+
+@pytest.mark.parametrize("name,probe", BENCH_BATCH)
+def test_bench_batch_launch(name, probe):
+    """The launches bench.py times, at their batch sizes (blockIdx.y > 0 in every kernel
+    template the benchmark runs, the workspace strides of a whole batch): adjoint identities over
+    the batch, every sample equal to its own batch-1 launch, one sample against the oracle."""
     fwd, bwd = _ops()
     from unipercept_amd import _lib
 
-    w = harness.WORKLOADS["cityscapes_1024x2048_fp32_b8"]
+    w = harness.WORKLOADS[name]
     value, shapes, lsi, loc, attn, g = harness.synth_inputs(
         w, "cuda", batch=w.batch, seed=1234, dist="R", oob_fraction=0.01
     )
+    f32 = w.dtype == "f32"
     hm = _lib.FLAG_VALUE_HEAD_MAJOR
     vt = torch.ops.unipercept.ms_deform_attn_value_head_major(value)
     out = fwd(vt, shapes, lsi, loc, attn, hm)
     gv, gl, ga = bwd(g, vt, shapes, lsi, loc, attn, hm)
     lhs = (out.double() * g.double()).sum()
     scale = (out.double().abs() * g.double().abs()).sum()
-    assert abs(lhs - (value.double() * gv.double()).sum()) / scale < 1e-6
-    assert abs(lhs - (attn.double() * ga.double()).sum()) / scale < 1e-6
+    # 16-bit results carry one rounding each (2^-9 relative, random sign): far below 1e-3 of the sum
+    tol = 1e-6 if f32 else 1e-3
+    assert abs(lhs - (value.double() * gv.double()).sum()) / scale < tol
+    assert abs(lhs - (attn.double() * ga.double()).sum()) / scale < tol
     for b in range(w.batch):
         sl = slice(b, b + 1)
         vb = vt[sl].contiguous()
@@ -202,11 +215,11 @@ def test_headline_batch8_launch():
         assert torch.equal(gl[sl], gl_b)
         assert torch.equal(ga[sl], ga_b)
         # the scatter's order of fp32 adds is not fixed from launch to launch
-        assert (gv[sl] - gv_b).abs().max() <= 1e-5 * gv_b.abs().max()
-    b = 5
-    sl = slice(b, b + 1)
+        rel = 1e-5 if f32 else 2.0**-7
+        assert (gv[sl].float() - gv_b.float()).abs().max() <= rel * gv_b.float().abs().max()
+    sl = slice(probe, probe + 1)
     want = _oracle64(value[sl], shapes, loc[sl], attn[sl], g[sl])
-    _check_against_oracle((out[sl], gv[sl], gl[sl], ga[sl]), want, "f32", loc[sl], w.levels)
+    _check_against_oracle((out[sl], gv[sl], gl[sl], ga[sl]), want, "f32" if f32 else "16", loc[sl], w.levels)
 
 
 @pytest.mark.parametrize("name,batch", FULL)

@@ -100,3 +100,67 @@ def test_oracle_rejects_half():
             np.zeros((1, 1, 1, 1), np.float16), np.array([[1, 1]]),
             np.zeros((1, 1, 1, 1, 1, 2), np.float16), np.zeros((1, 1, 1, 1, 1), np.float16),
         )
+
+
+def _pointrend_cases():
+    from pathlib import Path
+
+    # (the reference's known answer, pointrend_reftest_f32, holds a forward result only)
+    return sorted(
+        p.stem for p in (Path(__file__).parent / "golden").glob("pointrend_*.npz") if "reftest" not in p.stem
+    )
+
+
+@pytest.mark.parametrize("case", golden_cases() + _pointrend_cases())
+def test_oracle_under_sanitizers(case, tmp_path):
+    """The C oracles built with AddressSanitizer + UndefinedBehaviorSanitizer (host code only),
+    run on every golden vector through a file-driven program whose buffers are heap blocks of
+    exactly the case's sizes: no report, and the same numbers as the golden file."""
+    import subprocess
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    built = subprocess.run(["make", "-C", str(root / "oracle"), "sanitize_driver"], capture_output=True, text=True)
+    assert built.returncode == 0, built.stderr[-2000:]
+    z = np.load(root / "tests" / "golden" / f"{case}.npz")
+    src, dst = tmp_path / "case.bin", tmp_path / "result.bin"
+    if case.startswith("pointrend_"):
+        x = z["input"]
+        f64 = x.dtype == np.float64
+        n, c, h, w = x.shape
+        p = z["coords"].shape[1]
+        mode = {"bilinear": 0, "nearest": 1}[str(z["mode"])]
+        head = np.array([1, int(f64), n, c, h, w, p, mode, int(bool(z["align_corners"]))], dtype=np.int32)
+        blocks = [x, z["coords"].astype(x.dtype), z["grad_out"].astype(x.dtype)]
+        wants = [z["out"], z["grad_input"], z["grad_coords"]]
+        fa, ba = (2e-5, 2e-5) if not f64 else (1e-12, 1e-11)
+        scale = [max(1.0, float(np.abs(t).max())) for t in wants]
+    else:
+        v = z["value"]
+        f64 = v.dtype == np.float64
+        n, s, m, d = v.shape
+        _, q, _, l, p, _ = z["loc"].shape
+        shapes = z["shapes"].astype(np.int64)
+        hw = shapes[:, 0] * shapes[:, 1]
+        lsi = np.concatenate([[0], np.cumsum(hw)[:-1]]).astype(np.int64)
+        head = np.array([0, int(f64), n, s, m, d, q, l, p], dtype=np.int32)
+        blocks = [shapes, lsi, v, z["loc"], z["attn"], z["grad_out"]]
+        wants = [z["out"], z["grad_value"], z["grad_loc"], z["grad_attn"]]
+        fa, ba = _tol(case)
+        scale = [1.0] * 4
+    with open(src, "wb") as fh:
+        fh.write(head.tobytes())
+        for b in blocks:
+            fh.write(np.ascontiguousarray(b).tobytes())
+    run = subprocess.run(
+        [str(root / "oracle" / "sanitize_driver"), str(src), str(dst)], capture_output=True, text=True,
+        env={"ASAN_OPTIONS": "detect_leaks=1:abort_on_error=0", "UBSAN_OPTIONS": "print_stacktrace=1"},
+    )
+    assert run.returncode == 0 and "ERROR" not in run.stderr and "runtime error" not in run.stderr, run.stderr[-3000:]
+    raw = np.fromfile(dst, dtype=wants[0].dtype)
+    at = 0
+    for i, want in enumerate(wants):
+        got = raw[at : at + want.size].reshape(want.shape)
+        at += want.size
+        assert np.abs(got - want).max() <= (fa if i == 0 else ba) * scale[i], (case, i)
+    assert at == raw.size

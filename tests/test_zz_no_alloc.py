@@ -15,6 +15,21 @@ pytestmark = pytest.mark.gpu
 
 _CODE = {torch.float32: 0, torch.bfloat16: 2}
 
+_hip = None
+
+
+def _device_free_bytes() -> int:
+    """hipMemGetInfo's free bytes, asked of the HIP runtime itself: unlike PyTorch's allocator
+    statistics it moves with every hipMalloc / hipFree of the process, the library's included."""
+    global _hip
+    if _hip is None:
+        _hip = ctypes.CDLL("libamdhip64.so")
+        _hip.hipMemGetInfo.restype = ctypes.c_int
+        _hip.hipMemGetInfo.argtypes = [ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t)]
+    free, total = ctypes.c_size_t(0), ctypes.c_size_t(0)
+    assert _hip.hipMemGetInfo(ctypes.byref(free), ctypes.byref(total)) == 0
+    return free.value
+
 
 def _both(lib, case, dtype, flags=0):
     n, m, d, lq, levels, p = case
@@ -42,8 +57,17 @@ def _both(lib, case, dtype, flags=0):
     )
     assert rc == 0, rc
     gv2, gl2, ga2 = outputs()
+    # one call first, so that what is measured below is a call with the array's address already
+    # looked up and the kernels' code already on the device
+    rc = lib.msda_backward_noalloc(
+        grad_out.data_ptr(), value.data_ptr(), shapes.data_ptr(), lsi.data_ptr(), loc.data_ptr(),
+        attn.data_ptr(), None, gv2.data_ptr(), gl2.data_ptr(), ga2.data_ptr(), *dims, dv, dl, flags,
+        host, st,
+    )
+    assert rc == 0, rc
+    gv2, gl2, ga2 = outputs()
     torch.cuda.synchronize()
-    before = torch.cuda.memory_allocated()
+    before, free_before = torch.cuda.memory_allocated(), _device_free_bytes()
     rc = lib.msda_backward_noalloc(
         grad_out.data_ptr(), value.data_ptr(), shapes.data_ptr(), lsi.data_ptr(), loc.data_ptr(),
         attn.data_ptr(), None, gv2.data_ptr(), gl2.data_ptr(), ga2.data_ptr(), *dims, dv, dl, flags,
@@ -51,7 +75,9 @@ def _both(lib, case, dtype, flags=0):
     )
     assert rc == 0, rc
     torch.cuda.synchronize()
+    # neither PyTorch's allocator nor the device's free memory moved: no hipMalloc / hipFree
     assert torch.cuda.memory_allocated() == before
+    assert _device_free_bytes() == free_before
     # same kernels on the same inputs: grad_loc / grad_attn bit for bit; grad_value up to the
     # order of its fp32 adds (fp32: within the backward tolerance 1e-3 max-abs, in fact far
     # below; bf16: one rounding step of the result)

@@ -45,11 +45,6 @@ inline int check_common(int N, int S, int M, int D, int Lq, int L, int P, int dt
 
 inline int group_lanes(int D) { return D <= 8 ? 8 : D <= 16 ? 16 : D <= 32 ? 32 : 64; }
 
-inline int launch_status() {
-  const hipError_t e = hipGetLastError();
-  return e == hipSuccess ? MSDA_OK : static_cast<int>(e);
-}
-
 struct Dims {
   int N, S, M, D, Lq, L, P;
 };
@@ -62,8 +57,9 @@ int fwd_generic(const void* value, const int64_t* shapes, const int64_t* lsi, co
   const int G = group_lanes(d.D);
   const int64_t blocks = (groups + (256 / G) - 1) / (256 / G);
   if (blocks > INT32_MAX) return MSDA_ESHAPE;
+  Launches run;
 #define MSDA_LAUNCH(GG)                                                                          \
-  hipLaunchKernelGGL((fwd_generic_kernel<VT, LT, GG>), dim3(static_cast<unsigned>(blocks)),      \
+  run((fwd_generic_kernel<VT, LT, GG>), dim3(static_cast<unsigned>(blocks)),      \
                      dim3(256), 0, stream, static_cast<const VT*>(value), shapes, lsi,           \
                      static_cast<const LT*>(loc), static_cast<const LT*>(attn),                  \
                      static_cast<VT*>(out), groups, d.S, d.M, d.D, d.Lq, d.L, d.P)
@@ -74,7 +70,7 @@ int fwd_generic(const void* value, const int64_t* shapes, const int64_t* lsi, co
     default: MSDA_LAUNCH(64); break;
   }
 #undef MSDA_LAUNCH
-  return launch_status();
+  return run.rc;
 }
 
 // ---- generic backward -----------------------------------------------------------------------
@@ -94,8 +90,9 @@ int bwd_generic(const void* grad_out, const void* value, const int64_t* shapes, 
     const hipError_t e = hipMemsetAsync(acc, 0, static_cast<size_t>(total) * sizeof(GT), stream);
     if (e != hipSuccess) return static_cast<int>(e);
   }
+  Launches run;
 #define MSDA_LAUNCH(GG, SC)                                                                      \
-  hipLaunchKernelGGL((bwd_generic_kernel<VT, LT, GT, GG, SC>),                                   \
+  run((bwd_generic_kernel<VT, LT, GT, GG, SC>),                                   \
                      dim3(static_cast<unsigned>(blocks)), dim3(256), 0, stream,                  \
                      static_cast<const VT*>(grad_out), static_cast<const VT*>(value), shapes,    \
                      lsi, static_cast<const LT*>(loc), static_cast<const LT*>(attn), acc,        \
@@ -115,25 +112,22 @@ int bwd_generic(const void* grad_out, const void* value, const int64_t* shapes, 
   }
 #undef MSDA_LAUNCH_G
 #undef MSDA_LAUNCH
-  int rc = launch_status();
-  if (rc != MSDA_OK) return rc;
   if (deterministic) {
     const int64_t vb = (total + 255) / 256;
     if (vb > INT32_MAX) return MSDA_ESHAPE;
-    hipLaunchKernelGGL((bwd_value_gather_kernel<VT, LT>), dim3(static_cast<unsigned>(vb)),
+    run((bwd_value_gather_kernel<VT, LT>), dim3(static_cast<unsigned>(vb)),
                        dim3(256), 0, stream, static_cast<const VT*>(grad_out), shapes, lsi,
                        static_cast<const LT*>(loc), static_cast<const LT*>(attn),
                        static_cast<VT*>(grad_value), total, d.S, d.M, d.D, d.Lq, d.L, d.P);
-    return launch_status();
+    return run.rc;
   }
   if constexpr (!kDirect) {
     const int64_t cb = (total + 255) / 256;
     const unsigned grid = static_cast<unsigned>(cb < 8192 ? cb : 8192);
-    hipLaunchKernelGGL((convert_from_f32_kernel<VT>), dim3(grid), dim3(256), 0, stream,
+    run((convert_from_f32_kernel<VT>), dim3(grid), dim3(256), 0, stream,
                        static_cast<const float*>(workspace), static_cast<VT*>(grad_value), total);
-    rc = launch_status();
   }
-  return rc;
+  return run.rc;
 }
 
 inline bool needs_f32_image(int dtype_val) { return dtype_val == MSDA_BF16 || dtype_val == MSDA_F16; }
@@ -158,15 +152,33 @@ constexpr int kMaxDevices = 64;
 std::mutex scratch_mutex;
 void* scratch_ptr[kMaxDevices] = {};
 
-int noalloc_scratch(void** out) {
-  int dev = -1;
-  hipError_t e = hipGetDevice(&dev);
+// The array that belongs to the GPU the launch will run on: the device of `stream`, or the
+// current device for the default stream.
+int noalloc_scratch(hipStream_t stream, void** out) {
+  int cur = -1;
+  hipError_t e = hipGetDevice(&cur);
   if (e != hipSuccess) return static_cast<int>(e);
+  int dev = cur;
+  if (stream != nullptr) {
+    hipDevice_t sd;
+    e = hipStreamGetDevice(stream, &sd);
+    if (e != hipSuccess) return static_cast<int>(e);
+    dev = static_cast<int>(sd);
+  }
   if (dev < 0 || dev >= kMaxDevices) return MSDA_ENOALLOC;
   std::lock_guard<std::mutex> lock(scratch_mutex);
   if (scratch_ptr[dev] == nullptr) {
+    // the symbol resolves to the copy of the device that is current during the lookup
+    if (dev != cur) {
+      e = hipSetDevice(dev);
+      if (e != hipSuccess) return static_cast<int>(e);
+    }
     void* p = nullptr;
     e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+    if (dev != cur) {
+      const hipError_t back = hipSetDevice(cur);
+      if (e == hipSuccess) e = back;
+    }
     if (e != hipSuccess) return static_cast<int>(e);
     if (p == nullptr || reinterpret_cast<uintptr_t>(p) % 256 != 0) return MSDA_ENOALLOC;
     scratch_ptr[dev] = p;
@@ -299,24 +311,26 @@ int msda_value_relayout(const void* src, void* dst, const unsigned char* padding
   const int64_t blocks = (rows * chunks + 255) / 256;
   const unsigned grid = static_cast<unsigned>(blocks < 16384 ? blocks : 16384);
   // to head-major: src (N,S,M,.) -> dst (N,M,S,.); back: src (N,M,S,.) -> dst (N,S,M,.)
-  hipLaunchKernelGGL(relayout_rows_kernel, dim3(grid), dim3(256), 0,
+  Launches run;
+  run(relayout_rows_kernel, dim3(grid), dim3(256), 0,
                      static_cast<hipStream_t>(hip_stream), static_cast<const uint4*>(src),
                      static_cast<uint4*>(dst), padding_mask, rows, to_head_major ? S : M,
                      to_head_major ? M : S, chunks, to_head_major ? 1 : 0);
-  return launch_status();
+  return run.rc;
 }
 
 size_t msda_backward_workspace_bytes(int N, int S, int M, int D, int Lq, int L, int P,
                                      int dtype_val, int dtype_loc, int flags,
                                      const int64_t* shapes_host) {
   if (check_common(N, S, M, D, Lq, L, P, dtype_val, dtype_loc) != MSDA_OK) return 0;
-  if (flags & MSDA_FLAG_DETERMINISTIC) return 0;
+  const bool det = (flags & MSDA_FLAG_DETERMINISTIC) != 0;
   if (!(flags & MSDA_FLAG_GENERIC)) {
     const int64_t t = tuned_backward_workspace_bytes(
-        N, S, M, D, Lq, L, P, dtype_val, dtype_loc, !(flags & MSDA_FLAG_ATOMIC_SCATTER),
-        (flags & MSDA_FLAG_TILE_1D) ? nullptr : shapes_host);
+        N, S, M, D, Lq, L, P, dtype_val, dtype_loc, det || !(flags & MSDA_FLAG_ATOMIC_SCATTER),
+        (flags & MSDA_FLAG_TILE_1D) ? nullptr : shapes_host, det);
     if (t >= 0) return static_cast<size_t>(t);
   }
+  if (det) return 0;  // the per-destination gather needs none
   if (needs_f32_image(dtype_val)) return static_cast<size_t>(N) * S * M * D * sizeof(float);
   return 0;
 }
@@ -344,7 +358,7 @@ int msda_backward_noalloc(const void* grad_out, const void* value, const int64_t
   if (need > kNoAllocScratchBytes) return MSDA_ENOALLOC;
   void* ws = nullptr;
   if (need > 0) {
-    const int rc = noalloc_scratch(&ws);
+    const int rc = noalloc_scratch(static_cast<hipStream_t>(hip_stream), &ws);
     if (rc != MSDA_OK) return rc;
   }
   return backward_impl(grad_out, value, shapes_dev, lsi_dev, loc, attn, ref_points, grad_value,
@@ -367,7 +381,7 @@ int backward_impl(const void* grad_out, const void* value, const int64_t* shapes
       (!packed && (!attn || !grad_attn)) || (raw && !ref_points))
     return MSDA_ENULL;
   if (raw && !aligned(ref_points, 8)) return MSDA_EALIGN;
-  if (raw && ((flags & (MSDA_FLAG_DETERMINISTIC | MSDA_FLAG_GENERIC | MSDA_FLAG_ATOMIC_SCATTER)) ||
+  if (raw && ((flags & (MSDA_FLAG_GENERIC | MSDA_FLAG_ATOMIC_SCATTER)) ||
               !raw_points_supported(N, S, M, D, Lq, L, P, dtype_val, dtype_loc)))
     return MSDA_ELAYOUT;
   const int rc = check_common(N, S, M, D, Lq, L, P, dtype_val, dtype_loc);
@@ -387,13 +401,16 @@ int backward_impl(const void* grad_out, const void* value, const int64_t* shapes
   hipStream_t stream = static_cast<hipStream_t>(hip_stream);
   const bool det = (flags & MSDA_FLAG_DETERMINISTIC) != 0;
 
-  if (!det && !(flags & MSDA_FLAG_GENERIC)) {
+  // MSDA_FLAG_DETERMINISTIC: the binned path with its reproducible tile kernel where the shape
+  // has one (ignoring MSDA_FLAG_ATOMIC_SCATTER), else the generic per-destination gather
+  if (!(flags & MSDA_FLAG_GENERIC)) {
     const int t = tuned_backward(grad_out, value, shapes_dev, lsi_dev, loc, attn, grad_value,
                                  grad_loc, grad_attn, workspace, N, S, M, D, Lq, L, P, dtype_val,
-                                 dtype_loc, !(flags & MSDA_FLAG_ATOMIC_SCATTER),
+                                 dtype_loc, det || !(flags & MSDA_FLAG_ATOMIC_SCATTER),
                                  (flags & MSDA_FLAG_VALUE_HEAD_MAJOR) != 0, packed,
                                  (flags & MSDA_FLAG_TILE_1D) ? nullptr : shapes_host,
-                                 raw ? static_cast<const float*>(ref_points) : nullptr, stream);
+                                 raw ? static_cast<const float*>(ref_points) : nullptr,
+                                 (flags & 128) ? kPhaseGrad : (flags & 256) ? kPhaseBin : (kPhaseBin | kPhaseGrad), det, stream);
     if (t != kNotTuned) return t;
   }
   if ((flags & MSDA_FLAG_VALUE_HEAD_MAJOR) || packed) return MSDA_ELAYOUT;
@@ -441,8 +458,9 @@ int msda_points_forward(const void* raw, const void* ref_points, const int64_t* 
   if (blocks > INT32_MAX) return MSDA_ESHAPE;
   const size_t lds = points_lds_bytes(L, P, rpb, false);
   hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+  Launches run;
 #define MSDA_PF(RT, LT)                                                                       \
-  hipLaunchKernelGGL((points_forward_kernel<RT, LT>), dim3(static_cast<unsigned>(blocks)),    \
+  run((points_forward_kernel<RT, LT>), dim3(static_cast<unsigned>(blocks)),    \
                      dim3(256), lds, stream, static_cast<const RT*>(raw),                     \
                      static_cast<const LT*>(ref_points), shapes_dev, static_cast<LT*>(packed), \
                      rows, M, L, P, rpb)
@@ -456,7 +474,7 @@ int msda_points_forward(const void* raw, const void* ref_points, const int64_t* 
       break;
   }
 #undef MSDA_PF
-  return launch_status();
+  return run.rc;
 }
 
 int msda_points_backward(const void* grad_packed, const void* packed, const int64_t* shapes_dev,
@@ -475,8 +493,9 @@ int msda_points_backward(const void* grad_packed, const void* packed, const int6
   if (blocks > INT32_MAX) return MSDA_ESHAPE;
   const size_t lds = points_lds_bytes(L, P, rpb, true);
   hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+  Launches run;
 #define MSDA_PB(RT, LT)                                                                        \
-  hipLaunchKernelGGL((points_backward_kernel<RT, LT>), dim3(static_cast<unsigned>(blocks)),    \
+  run((points_backward_kernel<RT, LT>), dim3(static_cast<unsigned>(blocks)),    \
                      dim3(256), lds, stream, static_cast<const LT*>(grad_packed),              \
                      static_cast<const LT*>(packed), shapes_dev, static_cast<RT*>(grad_raw),   \
                      rows, L, P, rpb)
@@ -490,7 +509,7 @@ int msda_points_backward(const void* grad_packed, const void* packed, const int6
       break;
   }
 #undef MSDA_PB
-  return launch_status();
+  return run.rc;
 }
 
 int msda_point_sample_forward(const void* input, const void* coords, void* out, int N, int C,
@@ -506,8 +525,9 @@ int msda_point_sample_forward(const void* input, const void* coords, void* out, 
   int64_t blocks;
   if (!make_sample_grid(N, C, P, &g, &blocks, 256 * kSamplePPT)) return MSDA_ESHAPE;
   hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+  Launches run;
 #define MSDA_SF(T)                                                                              \
-  hipLaunchKernelGGL((point_sample_fwd_kernel<T>), dim3(static_cast<unsigned>(blocks)),         \
+  run((point_sample_fwd_kernel<T>), dim3(static_cast<unsigned>(blocks)),         \
                      dim3(256), 0, stream, static_cast<const T*>(input),                        \
                      static_cast<const T*>(coords), static_cast<T*>(out), C, H, W, P, g, mode,  \
                      align_corners ? 1 : 0)
@@ -518,7 +538,7 @@ int msda_point_sample_forward(const void* input, const void* coords, void* out, 
     default: MSDA_SF(f16_t); break;
   }
 #undef MSDA_SF
-  return launch_status();
+  return run.rc;
 }
 
 size_t msda_point_sample_workspace_bytes(int N, int C, int H, int W, int P, int dtype) {
@@ -577,8 +597,9 @@ int msda_point_sample_backward(const void* grad_out, const void* input, const vo
     err = hipMemsetAsync(grad_coords, 0, static_cast<size_t>(N) * P * 2 * e, stream);
     if (err != hipSuccess) return static_cast<int>(err);
   }
+  Launches run;
 #define MSDA_SB(T, SCATTER)                                                                     \
-  hipLaunchKernelGGL((point_sample_bwd_kernel<T, SCATTER>), dim3(static_cast<unsigned>(blocks)), \
+  run((point_sample_bwd_kernel<T, SCATTER>), dim3(static_cast<unsigned>(blocks)), \
                      dim3(256), 0, stream, static_cast<const T*>(grad_out),                     \
                      static_cast<const T*>(input), static_cast<const T*>(coords),               \
                      static_cast<T*>(grad_input), static_cast<T*>(grad_coords), C, H, W, P, g,  \
@@ -587,10 +608,10 @@ int msda_point_sample_backward(const void* grad_out, const void* input, const vo
   do {                                                                                          \
     const size_t lds = static_cast<size_t>(band_rows) * W * sizeof(double);                     \
     if (listed)                                                                                 \
-      hipLaunchKernelGGL((point_band_lists_kernel<T>), dim3(static_cast<unsigned>(N)),          \
+      run((point_band_lists_kernel<T>), dim3(static_cast<unsigned>(N)),          \
                          dim3(1024), 0, stream, static_cast<const T*>(coords), list, list_off,  \
                          H, P, band_rows, bg.per, mode, align_corners ? 1 : 0);                 \
-    hipLaunchKernelGGL((point_sample_bwd_band_kernel<T>),                                       \
+    run((point_sample_bwd_band_kernel<T>),                                       \
                        dim3(static_cast<unsigned>(band_blocks)), dim3(1024), lds, stream,       \
                        static_cast<const T*>(grad_out), static_cast<const T*>(coords),          \
                        static_cast<T*>(grad_input), list, list_off, C, H, W, P, bg, band_rows,  \
@@ -613,7 +634,7 @@ int msda_point_sample_backward(const void* grad_out, const void* input, const vo
   }
 #undef MSDA_SBAND
 #undef MSDA_SB
-  return launch_status();
+  return run.rc;
 }
 
 }  // extern "C"

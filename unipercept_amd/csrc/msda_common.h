@@ -4,7 +4,38 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <tuple>
+#include <utility>
+
 namespace msda {
+
+// ---- kernel launches ---------------------------------------------------------------------------
+// Launches through hipLaunchKernel and keeps ITS return code: the status a call reports is that
+// of its own launches, not whatever hipGetLastError() holds from earlier work of the thread
+// (PyTorch's or anyone else's), and nobody else's pending error is cleared.  After a failed
+// launch the later launches of the same call are skipped.
+struct Launches {
+  int rc = 0;  // 0 or the hipError_t of the first launch that failed
+
+  template <typename... KArgs, typename... Args>
+  void operator()(void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t lds_bytes,
+                  hipStream_t stream, Args... args) {
+    static_assert(sizeof...(KArgs) == sizeof...(Args), "argument count of the kernel");
+    if (rc != 0) return;
+    std::tuple<KArgs...> vals{static_cast<KArgs>(args)...};  // converted to the parameter types
+    void* ptrs[sizeof...(KArgs) > 0 ? sizeof...(KArgs) : 1];
+    fill(vals, ptrs, std::index_sequence_for<KArgs...>{});
+    const hipError_t e = hipLaunchKernel(reinterpret_cast<const void*>(kernel), grid, block, ptrs,
+                                         lds_bytes, stream);
+    rc = e == hipSuccess ? 0 : static_cast<int>(e);
+  }
+
+ private:
+  template <typename Tuple, size_t... I>
+  static void fill(Tuple& vals, void** out, std::index_sequence<I...>) {
+    ((out[I] = const_cast<void*>(static_cast<const void*>(&std::get<I>(vals)))), ...);
+  }
+};
 
 // ---- element types -------------------------------------------------------------------------
 struct bf16_t {

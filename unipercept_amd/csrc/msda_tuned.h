@@ -251,7 +251,10 @@ struct BinPlan {
   int tile2d;       // tile geometry (see above)
   int tw_shift;     // tile2d: log2 of the patch width (the height is TS / width)
   int in_order;     // always 1; a run-time value on purpose, see the value gather of bwd_query_kernel
+  int phase;        // query kernel: bit 0 = bin the scatter (directory + records), bit 1 = gradients
+  int q_per_block;  // queries whose records one region holds (= qb)
 };
+constexpr int kPhaseBin = 1, kPhaseGrad = 2;
 
 struct TileMap {  // tile2d only: first tile id and tiles per row of every level
   int tstart[kMaxLevelsTuned + 1];
@@ -802,7 +805,11 @@ __global__ __launch_bounds__(256, MSDA_K3_MINWAVES) void bwd_query_kernel(
   }
   MSDA_STAMP(1);  // point loads issued
 
+  // KPC > 0: the directory and the records may exist already (written by an earlier launch of
+  // this kernel with kPhaseBin only, on the same points): then only the gradients are left
+  const bool do_bin = KPC == 0 || (plan.phase & kPhaseBin) != 0;
   if (MODE == 1 && !(kAblate & 1)) {
+   if (do_bin) {
     // ---- count the records of this workgroup per destination tile ----
     for (int t = threadIdx.x; t < plan.n_tiles; t += 256) tile_cnt[t] = 0;
     __syncthreads();
@@ -920,6 +927,10 @@ __global__ __launch_bounds__(256, MSDA_K3_MINWAVES) void bwd_query_kernel(
         for (uint32_t t = threadIdx.x; t < n_copy; t += 256) emit.records[t] = emit.lds_image[t];
         __syncthreads();
       }
+    }
+   }  // do_bin
+    if constexpr (KPC > 0) {
+      if (!(plan.phase & kPhaseGrad)) return;  // binning only (uniform)
       // then the points of the second and third chunk are parked in LDS (the gather loop needs
       // the registers) and the first chunk is staged
 #pragma unroll
@@ -1427,6 +1438,204 @@ __global__ __launch_bounds__(256) void bwd_tile_gather_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------
+// Backward, destination side, reproducible form (MSDA_FLAG_DETERMINISTIC on the binned path).
+//
+// The fast tile kernel adds a position's contributions in whatever order LDS atomics ranked them:
+// the order of the records inside a (query block, tile) run, the order of the runs, and the
+// order of a position's entries inside a round all change from launch to launch, and with them
+// the last bits of the fp32 sums.  Here every one of those orders is fixed by the data:
+//   * the runs of the tile are taken in query-block order (empty ones included);
+//   * a round is a set of WHOLE runs (as many consecutive ones as fit R records), so which
+//     records share a round does not depend on the order inside a run; a run longer than R is
+//     taken in passes over sub-ranges of its query block (R / (L*P) queries each: a query sends at
+//     most L*P records to one tile), each pass scanning the whole run;
+//   * inside a round, every position's entry list is sorted by (query, weight bits) before it is
+//     walked — entries that compare equal contribute identical products, so their order is free.
+// Two launches on the same inputs therefore give bit-equal grad_value.  About twice the fast
+// kernel's time (records are read and their footprints computed twice, plus the sort).
+// ---------------------------------------------------------------------------------------------
+template <typename VT, int G>
+__global__ __launch_bounds__(256) void bwd_tile_gather_det_kernel(
+    const VT* __restrict__ grad_out, const int64_t* __restrict__ shapes,
+    const int64_t* __restrict__ lsi, const uint4* __restrict__ records,
+    const uint2* __restrict__ dir, VT* __restrict__ grad_value, int S, int M, int Lq, int L,
+    int LP, BinPlan plan, int g_head_major) {
+  constexpr int CPL = Chunk<VT>::kCPL;
+  constexpr int D = G * CPL;
+  constexpr int PL = 4;
+  constexpr int TS = 256 / PL;
+  constexpr int NCH = D / (PL * CPL);
+  constexpr int R = 512;  // records per round (4 * R entries)
+  constexpr int U = 3;
+  constexpr int ROWB = D * sizeof(VT);
+  static_assert(TS == 64, "the bucket scan is one wave wide");
+  extern __shared__ uint4 lds[];
+  __shared__ LevelInfo lv[kMaxLevelsTuned];
+  __shared__ TileMap tm;
+  __shared__ uint32_t scan_tmp[4];
+  __shared__ int tile_level_s, tile_y0_s, tile_x0_s;
+
+  uint2* entries = reinterpret_cast<uint2*>(lds);                  // 4 * R, in fill order
+  uint2* sorted = entries + 4 * R;                                 // 4 * R, in walk order
+  uint32_t* cnt = reinterpret_cast<uint32_t*>(sorted + 4 * R);     // TS: counts, then cursors
+  uint32_t* start = cnt + TS;                                      // TS + 1
+  uint32_t* run_first = start + TS + 1;                            // n_qblocks + 1
+  uint32_t* run_base = run_first + plan.n_qblocks + 1;             // n_qblocks
+
+  const int b = blockIdx.y;
+  const int m = blockIdx.x % M;
+  const int tile = plan.n_tiles - 1 - blockIdx.x / M;
+  const int64_t slab = static_cast<int64_t>(b) * M + m;
+  if (threadIdx.x < L) lv[threadIdx.x] = load_level(shapes, lsi, threadIdx.x, S);
+  __syncthreads();
+  if (plan.tile2d && threadIdx.x == 0) {
+    build_tile_map(lv, L, plan, tm);
+    locate_tile(tm, L, plan, tile, tile_level_s, tile_y0_s, tile_x0_s);
+  }
+  // every query block's run of this tile, in query-block order (length 0 when it has none)
+  const int n_runs = plan.n_qblocks;
+  for (int qbk = threadIdx.x; qbk < n_runs; qbk += 256) {
+    const uint2 e = dir[(slab * plan.n_qblocks + qbk) * plan.n_tiles + tile];
+    const bool ok = e.y != 0 && e.x <= plan.region && e.y <= plan.region - e.x;
+    run_first[qbk] = ok ? e.y : 0u;
+    run_base[qbk] = static_cast<uint32_t>(qbk) * plan.region + (ok ? e.x : 0u);
+  }
+  const uint32_t total = block_exclusive_scan(run_first, n_runs, scan_tmp);
+  if (threadIdx.x == 0) run_first[n_runs] = total;
+  __syncthreads();
+
+  const uint4* slab_records = records + slab * plan.n_qblocks * static_cast<int64_t>(plan.region);
+  const char* go_slab = reinterpret_cast<const char*>(grad_out) +
+                        (g_head_major ? slab * Lq : static_cast<int64_t>(b) * Lq * M + m) * ROWB;
+  const uint32_t tile_u = static_cast<uint32_t>(tile);
+  const int pg = threadIdx.x / PL, pl = threadIdx.x % PL;
+  const uint32_t q_stride = static_cast<uint32_t>(g_head_major ? 1 : M) * ROWB;
+  // largest r in [0, n_runs] with run_first[r] <= x
+  const auto last_start_le = [&](uint32_t x) {
+    int lo = 0, hi = n_runs + 1;
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (run_first[mid] <= x) lo = mid; else hi = mid;
+    }
+    return lo;
+  };
+
+  float sum[NCH][CPL];
+#pragma unroll
+  for (int j = 0; j < NCH; ++j)
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) sum[j][c] = 0.f;
+
+  const uint32_t q_sub = static_cast<uint32_t>(max(1, R / max(LP, 1)));  // queries per pass of a long run
+  uint32_t base = 0, sub = 0;
+  while (base < total) {  // (uniform)
+    // ---- the round: records [lo, hi) of the tile's list, queries [q_lo, q_hi) ----
+    uint32_t lo = base, hi, q_lo = 0u, q_hi = 0xffffffffu, next_base, next_sub = 0u;
+    const int r_end = last_start_le(base + R);  // run_first[r_end] <= base + R
+    if (run_first[r_end] > base) {
+      hi = run_first[r_end];  // whole runs
+      next_base = hi;
+    } else {
+      const int r0 = last_start_le(base);  // the (non-empty) run that starts at base: longer than R
+      hi = run_first[r0 + 1];
+      q_lo = static_cast<uint32_t>(r0) * plan.q_per_block + sub * q_sub;
+      q_hi = q_lo + q_sub;
+      const bool last = (sub + 1) * q_sub >= static_cast<uint32_t>(plan.q_per_block);
+      next_base = last ? hi : base;
+      next_sub = last ? 0u : sub + 1;
+    }
+    if (threadIdx.x < TS) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    // the records are visited twice with the same arithmetic: to count, then to fill
+    const auto visit = [&](auto&& corner) {
+      for (uint32_t i = lo + threadIdx.x; i < hi; i += 256) {
+        const int r = last_start_le(i);
+        const uint4 rec = slab_records[run_base[r] + (i - run_first[r])];
+        const uint32_t q = rec.x & 0x0fffffffu;
+        if (q >= static_cast<uint32_t>(Lq) || q < q_lo || q >= q_hi) continue;
+        const int l = static_cast<int>(rec.x >> 28);
+        const LevelInfo L_ = lv[l];
+        const float a = __uint_as_float(rec.y);
+        const Footprint<float> f =
+            footprint<float, true>(__uint_as_float(rec.z), __uint_as_float(rec.w), L_.H, L_.W);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          uint32_t t, local;
+          pixel_tile(plan, tm, L_, l, f.cy[k >> 1], f.cx[k & 1], t, local);
+          if (f.valid[k] && t == tile_u) corner(local, q, a * f.w[k]);
+        }
+      }
+    };
+    visit([&](uint32_t local, uint32_t, float) { atomicAdd(&cnt[local], 1u); });
+    __syncthreads();
+    if (threadIdx.x < TS) {
+      const uint32_t c = cnt[threadIdx.x];
+      const uint32_t incl = wave_inclusive_scan(c);
+      start[threadIdx.x] = incl - c;
+      cnt[threadIdx.x] = incl - c;
+      if (threadIdx.x == TS - 1) start[TS] = incl;
+    }
+    __syncthreads();
+    visit([&](uint32_t local, uint32_t q, float w) {
+      const uint32_t at = atomicAdd(&cnt[local], 1u);
+      if (at < 4u * R) entries[at] = make_uint2(q, __float_as_uint(w));
+    });
+    __syncthreads();
+    // ---- sort the list of this lane group's position by (query, weight bits): rank sort ----
+    const uint32_t e0 = min(start[pg], 4u * R), e1 = min(start[pg + 1], 4u * R);
+    for (uint32_t i = e0 + pl; i < e1; i += PL) {
+      const uint2 me = entries[i];
+      uint32_t rank = 0;
+      for (uint32_t j = e0; j < e1; ++j) {
+        const uint2 o = entries[j];
+        const bool before = o.x < me.x || (o.x == me.x && (o.y < me.y || (o.y == me.y && j < i)));
+        rank += before ? 1u : 0u;
+      }
+      sorted[e0 + rank] = me;
+    }
+    __syncthreads();
+    // ---- walk, in list order ----
+    for (uint32_t e = e0; e < e1; e += U) {
+      float w[U], rv[U][NCH][CPL];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const uint2 ent = sorted[min(e + u, e1 - 1)];
+        w[u] = e + u < e1 ? __uint_as_float(ent.y) : 0.f;
+        const char* row = go_slab + (__umul24(ent.x, q_stride) + pl * 16u);
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) Chunk<VT>::load(row + j * PL * 16, rv[u][j]);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int j = 0; j < NCH; ++j)
+#pragma unroll
+          for (int c = 0; c < CPL; ++c) sum[j][c] = fmaf(w[u], rv[u][j][c], sum[j][c]);
+    }
+    __syncthreads();  // the next round reuses cnt, entries and sorted
+    base = next_base;
+    sub = next_sub;
+  }
+
+  int64_t pos;
+  if (plan.tile2d) {
+    const int l = tile_level_s;
+    if (l < 0) return;
+    const int yy = tile_y0_s + (pg >> plan.tw_shift);
+    const int xx = tile_x0_s + (pg & ((1 << plan.tw_shift) - 1));
+    if (yy >= lv[l].H || xx >= lv[l].W) return;
+    pos = lv[l].start + static_cast<int64_t>(yy) * lv[l].W + xx;
+  } else {
+    pos = static_cast<int64_t>(tile) * TS + pg;
+  }
+  if (pos >= S) return;
+  char* dst = reinterpret_cast<char*>(grad_value) +
+              (((static_cast<int64_t>(b) * S + pos) * M + m) * D) * sizeof(VT) + pl * 16;
+#pragma unroll
+  for (int j = 0; j < NCH; ++j) Chunk<VT>::store(dst + j * PL * 16, sum[j]);
+}
+
+// ---------------------------------------------------------------------------------------------
 // Host-side dispatch
 // ---------------------------------------------------------------------------------------------
 template <typename VT>
@@ -1462,6 +1671,9 @@ inline bool tuned_shape_ok(int N, int S, int M, int D, int Lq, int L, int P, int
       static_cast<int64_t>(Lq) * M * D * esize > static_cast<int64_t>(UINT32_MAX))
     return false;
   if (N > 65535) return false;
+  // rows of a query block (up to 192 queries x M heads) and their element offsets are formed
+  // with 24-bit multiplies and 32-bit sums as well
+  if (M > 65535) return false;
   const int GPB = 256 / (2 * G);  // fewest queries per workgroup of any kernel
   if ((static_cast<int64_t>(Lq) + GPB - 1) / GPB * M > INT32_MAX) return false;
   *G_out = G;
@@ -1564,6 +1776,8 @@ inline bool make_bin_plan(int N, int S, int M, int D, int Lq, int L, int P, int 
   plan->tile2d = tile2d;
   plan->tw_shift = tw_shift;
   plan->in_order = 1;
+  plan->phase = kPhaseBin | kPhaseGrad;
+  plan->q_per_block = qb;
   *dir_bytes = (static_cast<size_t>(dir_b) + 255) & ~static_cast<size_t>(255);
   *rec_bytes = static_cast<size_t>(rec_b);
   return true;
@@ -1629,8 +1843,9 @@ int tuned_forward_typed(const void* value, const int64_t* shapes, const int64_t*
   const dim3 grid(static_cast<unsigned>((Lq + GPB - 1) / GPB) * M, N);
   const int LPB = stage_points_per_pass(GQ, L * P, stage_slots(kStageFwd));
   const size_t lds = static_cast<size_t>(GPB) * group_stride_slots(LPB, 2) * 16;
+  Launches run;
 #define MSDA_TF(GG, PP)                                                                         \
-  hipLaunchKernelGGL((fwd_tuned_kernel<VT, LT, GG, PP>), grid, dim3(256), lds, stream,          \
+  run((fwd_tuned_kernel<VT, LT, GG, PP>), grid, dim3(256), lds, stream,          \
                      static_cast<const VT*>(value), shapes, lsi, static_cast<const LT*>(loc),   \
                      static_cast<const LT*>(attn), static_cast<VT*>(out), S, M, Lq, L, P, LPB,   \
                      head_major ? 1 : 0, rs, ref)
@@ -1646,8 +1861,7 @@ int tuned_forward_typed(const void* value, const int64_t* shapes, const int64_t*
     default: MSDA_TF(16, false); break;
   }
 #undef MSDA_TF
-  const hipError_t e = hipGetLastError();
-  return e == hipSuccess ? 0 : static_cast<int>(e);
+  return run.rc;
 }
 
 inline int tuned_forward(const void* value, const int64_t* shapes, const int64_t* lsi,
@@ -1677,13 +1891,14 @@ inline size_t g_copy_bytes(int N, int M, int D, int Lq, int dtype_val) {
 
 inline int64_t tuned_backward_workspace_bytes(int N, int S, int M, int D, int Lq, int L, int P,
                                               int dtype_val, int dtype_loc, bool allow_binned,
-                                              const int64_t* levels_host) {
+                                              const int64_t* levels_host, bool det = false) {
   int G;
   if (!tuned_shape_ok(N, S, M, D, Lq, L, P, dtype_val, dtype_loc, &G)) return -1;
   BinPlan plan;
   size_t dir_b, rec_b;
   if (allow_binned && make_bin_plan(N, S, M, D, Lq, L, P, G, levels_host, &plan, &dir_b, &rec_b))
     return static_cast<int64_t>(dir_b + rec_b + g_copy_bytes(N, M, D, Lq, dtype_val));
+  if (det) return -1;  // reproducible form: binned path only, else the caller's generic gather
   if (dtype_val == 0) return 0;
   return static_cast<int64_t>(N) * S * M * D * 4;  // fp32 accumulation image of grad_value
 }
@@ -1693,8 +1908,8 @@ int tuned_backward_typed(const void* grad_out, const void* value, const int64_t*
                          const int64_t* lsi, const void* loc, const void* attn, void* grad_value,
                          void* grad_loc, void* grad_attn, void* workspace, int N, int S, int M,
                          int D, int Lq, int L, int P, int G, bool allow_binned, bool head_major,
-                         bool packed, const int64_t* levels_host, const float* ref,
-                         hipStream_t stream) {
+                         bool packed, const int64_t* levels_host, const float* ref, int phase,
+                         bool det, hipStream_t stream) {
   const PointRows rs = packed ? PointRows{3 * L * P, 3 * L * P} : PointRows{2 * L * P, L * P};
   if (packed) {  // the weights (and their gradient) follow the pairs inside each packed row
     attn = static_cast<const LT*>(loc) + 2 * L * P;
@@ -1716,9 +1931,14 @@ int tuned_backward_typed(const void* grad_out, const void* value, const int64_t*
     kpc = GQ == 4 ? (LP <= 12 ? 3 : 4) : 2;  // ceil(GPB * LP / 256), rounded up to a built variant
     LPB = LP;
   }
-  hipError_t e;
+  Launches run;
   // raw points are handled by the register-resident form of the query kernel only
   if (ref != nullptr && (kpc == 0 || MSDA_K3_DEPTH != 2)) return MSDA_TUNED_ELAYOUT;
+  // so is the split of binning and gradients into two launches
+  if (phase != (kPhaseBin | kPhaseGrad) && (kpc == 0 || !binned)) return MSDA_TUNED_ELAYOUT;
+  plan.phase = phase;
+  // the reproducible form exists for the binned path only (the caller falls back otherwise)
+  if (det && !binned) return kNotTuned;
 
   if (binned) {
     uint2* dir = static_cast<uint2*>(workspace);
@@ -1739,11 +1959,18 @@ int tuned_backward_typed(const void* grad_out, const void* value, const int64_t*
     constexpr int RPT = 2;
     const size_t tlds = 4 * 256 * static_cast<size_t>(RPT) * 8 + (3 * TSz + 1) * 4 +
                         (2 * static_cast<size_t>(plan.n_qblocks) + 1) * 4;
+    // reproducible form: two entry arrays of 4 * 512, one count array
+    const size_t dlds = 2 * 4 * 512 * 8 + (2 * TSz + 1) * 4 +
+                        (2 * static_cast<size_t>(plan.n_qblocks) + 1) * 4;
 #define MSDA_TILE(GG, RR, UU)                                                                    \
-  hipLaunchKernelGGL((bwd_tile_gather_kernel<VT, GG, RR, UU>), tgrid, dim3(256), tlds, stream,   \
+  run((bwd_tile_gather_kernel<VT, GG, RR, UU>), tgrid, dim3(256), tlds, stream,   \
                      g_copy ? static_cast<const VT*>(g_copy) : static_cast<const VT*>(grad_out), \
                      shapes, lsi, records, dir, static_cast<VT*>(grad_value), S, M, Lq, L, plan, \
                      g_copy ? 1 : 0)
+#define MSDA_TILE_DET(GG)                                                                        \
+  run((bwd_tile_gather_det_kernel<VT, GG>), tgrid, dim3(256), dlds, stream,                      \
+      g_copy ? static_cast<const VT*>(g_copy) : static_cast<const VT*>(grad_out), shapes, lsi,   \
+      records, dir, static_cast<VT*>(grad_value), S, M, Lq, L, LP, plan, g_copy ? 1 : 0)
 #define MSDA_TQ(GG, KK)                                                                          \
   if ((KK) > 0 && plan.qb == 128) {                                                              \
     MSDA_TQB(GG, KK, ((KK) > 0 ? 128 : 192));                                                    \
@@ -1751,7 +1978,7 @@ int tuned_backward_typed(const void* grad_out, const void* value, const int64_t*
     MSDA_TQB(GG, KK, 192);                                                                       \
   }
 #define MSDA_TQB(GG, KK, QQ)                                                                     \
-  hipLaunchKernelGGL((bwd_query_kernel<VT, LT, GG, 1, KK, QQ>), qgrid, dim3(256), qlds, stream,  \
+  run((bwd_query_kernel<VT, LT, GG, 1, KK, QQ>), qgrid, dim3(256), qlds, stream,  \
                      static_cast<const VT*>(grad_out), static_cast<const VT*>(value), shapes,    \
                      lsi, static_cast<const LT*>(loc), static_cast<const LT*>(attn),             \
                      static_cast<LT*>(grad_loc), static_cast<LT*>(grad_attn),                    \
@@ -1769,7 +1996,13 @@ int tuned_backward_typed(const void* grad_out, const void* value, const int64_t*
   } else {                                                                                       \
     MSDA_TQ(GG, 2);                                                                              \
   }                                                                                              \
-  MSDA_TILE(GG, RPT, UU)
+  if (phase & kPhaseGrad) {                                                                      \
+    if (det) {                                                                                   \
+      MSDA_TILE_DET(GG);                                                                         \
+    } else {                                                                                     \
+      MSDA_TILE(GG, RPT, UU);                                                                    \
+    }                                                                                            \
+  }
     switch (G) {
       case 4: MSDA_TB(4, 3); break;
       case 8: MSDA_TB(8, 3); break;
@@ -1779,8 +2012,8 @@ int tuned_backward_typed(const void* grad_out, const void* value, const int64_t*
 #undef MSDA_TQ
 #undef MSDA_TQB
 #undef MSDA_TILE
-    e = hipGetLastError();
-    return e == hipSuccess ? 0 : static_cast<int>(e);
+#undef MSDA_TILE_DET
+    return run.rc;
   }
 
   // fp32-atomic fallback (very long sequences); it indexes grad_value with the value offsets,
@@ -1797,10 +2030,10 @@ int tuned_backward_typed(const void* grad_out, const void* value, const int64_t*
   const int64_t total = static_cast<int64_t>(N) * S * M * D;
   constexpr bool kDirect = sizeof(VT) == 4;
   float* acc = kDirect ? static_cast<float*>(grad_value) : static_cast<float*>(workspace);
-  e = hipMemsetAsync(acc, 0, static_cast<size_t>(total) * 4, stream);
+  const hipError_t e = hipMemsetAsync(acc, 0, static_cast<size_t>(total) * 4, stream);
   if (e != hipSuccess) return static_cast<int>(e);
 #define MSDA_TB(GG)                                                                              \
-  hipLaunchKernelGGL((bwd_query_kernel<VT, LT, GG, 0>), grid, dim3(256), lds, stream,            \
+  run((bwd_query_kernel<VT, LT, GG, 0>), grid, dim3(256), lds, stream,            \
                      static_cast<const VT*>(grad_out), static_cast<const VT*>(value), shapes,    \
                      lsi, static_cast<const LT*>(loc), static_cast<const LT*>(attn),             \
                      static_cast<LT*>(grad_loc), static_cast<LT*>(grad_attn), acc,               \
@@ -1813,18 +2046,14 @@ int tuned_backward_typed(const void* grad_out, const void* value, const int64_t*
     default: MSDA_TB(16); break;
   }
 #undef MSDA_TB
-  e = hipGetLastError();
-  if (e != hipSuccess) return static_cast<int>(e);
   if constexpr (!kDirect) {
     const int64_t total8 = total / 8;  // D is a multiple of 8 on this path
     const int64_t cb = (total8 + 255) / 256;
-    hipLaunchKernelGGL((convert_f32_image_kernel<VT>),
+    run((convert_f32_image_kernel<VT>),
                        dim3(static_cast<unsigned>(cb < 4096 ? cb : 4096)), dim3(256), 0, stream,
                        static_cast<const float*>(workspace), static_cast<VT*>(grad_value), total8);
-    e = hipGetLastError();
-    if (e != hipSuccess) return static_cast<int>(e);
   }
-  return 0;
+  return run.rc;
 }
 
 inline int tuned_backward(const void* grad_out, const void* value, const int64_t* shapes,
@@ -1832,7 +2061,8 @@ inline int tuned_backward(const void* grad_out, const void* value, const int64_t
                           void* grad_loc, void* grad_attn, void* workspace, int N, int S, int M,
                           int D, int Lq, int L, int P, int dtype_val, int dtype_loc,
                           bool allow_binned, bool head_major, bool packed,
-                          const int64_t* levels_host, const float* ref, hipStream_t stream) {
+                          const int64_t* levels_host, const float* ref, int phase, bool det,
+                          hipStream_t stream) {
   int G;
   if (!tuned_shape_ok(N, S, M, D, Lq, L, P, dtype_val, dtype_loc, &G)) return kNotTuned;
   if (!all_aligned16({value, grad_out, grad_value, workspace})) return kNotTuned;
@@ -1841,7 +2071,7 @@ inline int tuned_backward(const void* grad_out, const void* value, const int64_t
     return kNotTuned;
 #define MSDA_ARGS                                                                               \
   grad_out, value, shapes, lsi, loc, attn, grad_value, grad_loc, grad_attn, workspace, N, S, M, \
-      D, Lq, L, P, G, allow_binned, head_major, packed, levels_host, ref, stream
+      D, Lq, L, P, G, allow_binned, head_major, packed, levels_host, ref, phase, det, stream
   if (dtype_val == 0) return tuned_backward_typed<float, float>(MSDA_ARGS);
   if (dtype_val == 2)
     return dtype_loc == 0 ? tuned_backward_typed<bf16_t, float>(MSDA_ARGS)

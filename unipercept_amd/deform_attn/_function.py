@@ -15,17 +15,18 @@ from torch.autograd.function import once_differentiable
 from .. import _lib
 from . import _ops
 
-# The reproducible grad_value path (MSDA_FLAG_DETERMINISTIC) walks all Lq*P points of a level
-# for every grad_value element: fine for gradcheck-sized problems, effectively a hang at
-# benchmark sizes.  fp64 exists for gradcheck; below this much work it takes that path, so that
-# two backward passes agree bitwise (gradcheck's default nondet_tol is 0).  The same limit bounds
-# what `torch.use_deterministic_algorithms(True)` may route there.
+# Reproducible grad_value (MSDA_FLAG_DETERMINISTIC).  Shapes the tuned kernels bin (every benchmark
+# shape) keep the binned path and swap in a tile kernel that adds every position's contributions in
+# an order fixed by the data: about twice that kernel's time, any size.  Other shapes (fp64, odd
+# head dims) fall back to a per-destination gather that walks all Lq*P points of a level for every
+# grad_value element: fine for gradcheck-sized problems, effectively a hang at benchmark sizes,
+# hence the work limit.  fp64 exists for gradcheck; below the limit it takes that path unasked, so
+# that two backward passes agree bitwise (gradcheck's default nondet_tol is 0).
 _DET_WORK_LIMIT = 1 << 31
 
 
-def backward_flags(value: torch.Tensor, sampling_locations: torch.Tensor) -> int:
-    """Flags of the backward launch.  Evaluated ONCE, in the forward: the layout choices made
-    there (per-head value copy, packed points) must match the kernels the backward will run."""
+def route_flags() -> int:
+    """Experiment switches of the Python layer (environment): kernels to force for A/B runs."""
     flags = 0
     if os.environ.get("MSDA_FORCE_GENERIC") == "1":
         flags |= _lib.FLAG_GENERIC
@@ -33,23 +34,41 @@ def backward_flags(value: torch.Tensor, sampling_locations: torch.Tensor) -> int
         flags |= _lib.FLAG_ATOMIC_SCATTER
     if os.environ.get("MSDA_TILE_1D") == "1":
         flags |= _lib.FLAG_TILE_1D
+    return flags
+
+
+def deterministic_requested() -> bool:
+    """MSDA_DETERMINISTIC=1, or torch.use_deterministic_algorithms(True) unless MSDA_DETERMINISTIC=0."""
     det = os.environ.get("MSDA_DETERMINISTIC")
+    return det == "1" or (det != "0" and torch.are_deterministic_algorithms_enabled())
+
+
+def backward_flags(
+    value: torch.Tensor, sampling_locations: torch.Tensor, needs_backward: bool = True
+) -> int:
+    """Flags of the backward launch.  Evaluated ONCE, in the forward: the layout choices made
+    there (per-head value copy, packed points) must match the kernels the backward will run.
+    `needs_backward`: whether a backward can follow at all (an input requires grad) — a forward
+    under no_grad never alerts about the backward's reproducibility."""
+    flags = route_flags()
     lq, p = sampling_locations.shape[1], sampling_locations.shape[4]
     small = value.numel() * lq * p <= _DET_WORK_LIMIT
-    if det == "1":
-        flags |= _lib.FLAG_DETERMINISTIC
-    elif det != "0" and torch.are_deterministic_algorithms_enabled():
-        if small:
+    binned = (
+        value.is_cuda
+        and not flags & _lib.FLAG_GENERIC
+        and _ops.head_major_supported(value, sampling_locations)
+    )
+    if deterministic_requested():
+        if binned or small or os.environ.get("MSDA_DETERMINISTIC") == "1":
             flags |= _lib.FLAG_DETERMINISTIC
-        else:
-            # the binned scatter uses no float atomics, but the order in which a position's
-            # contributions are added is not fixed from launch to launch: say so the way
-            # PyTorch's own non-deterministic ops do (raises unless warn_only)
+        elif needs_backward:
+            # no reproducible kernel for this shape at this size: say so the way PyTorch's own
+            # non-deterministic ops do (raises unless warn_only)
             _alert_not_deterministic(
-                "ms_deform_attn backward at this size (grad_value summation order; set "
-                "MSDA_DETERMINISTIC=1 to force the slow reproducible path)"
+                "ms_deform_attn backward for this shape at this size (grad_value by float "
+                "atomics; set MSDA_DETERMINISTIC=1 to force the slow reproducible gather)"
             )
-    elif det != "0" and value.dtype == torch.float64 and small:
+    elif os.environ.get("MSDA_DETERMINISTIC") != "0" and value.dtype == torch.float64 and small:
         flags |= _lib.FLAG_DETERMINISTIC
     return flags
 
@@ -72,12 +91,23 @@ def forward_flags() -> int:
     return _lib.FLAG_GENERIC if os.environ.get("MSDA_FORCE_GENERIC") == "1" else 0
 
 
+def fused_route_flags() -> int:
+    """Backward flags of the routes that hand the kernels a per-head value copy (made by the
+    caller) and packed or raw points: those routes exist only for shapes the tuned kernels bin, so
+    a request for reproducible gradients keeps them and selects the reproducible tile kernel."""
+    flags = _lib.FLAG_VALUE_HEAD_MAJOR | (route_flags() & _lib.FLAG_TILE_1D)
+    if deterministic_requested():
+        flags |= _lib.FLAG_DETERMINISTIC
+    return flags
+
+
 def use_head_major(value: torch.Tensor, sampling_locations: torch.Tensor, bwd_flags: int) -> bool:
     """The fast path re-lays value out per head once and gathers from that copy in both passes."""
     if os.environ.get("MSDA_NO_HEAD_MAJOR") == "1":
         return False
-    if bwd_flags & (_lib.FLAG_GENERIC | _lib.FLAG_DETERMINISTIC | _lib.FLAG_ATOMIC_SCATTER):
+    if bwd_flags & (_lib.FLAG_GENERIC | _lib.FLAG_ATOMIC_SCATTER):
         return False
+    # (with MSDA_FLAG_DETERMINISTIC the shapes that pass this test run the binned path too)
     return value.is_cuda and _ops.head_major_supported(value, sampling_locations)
 
 
@@ -98,7 +128,7 @@ class MultiScaleDeformAttnFunction(torch.autograd.Function):
         )
         ctx.im2col_step = int(im2col_step)
         fflags = forward_flags()
-        bflags = backward_flags(value, sampling_locations)
+        bflags = backward_flags(value, sampling_locations, any(ctx.needs_input_grad))
         ctx.head_major = use_head_major(value, sampling_locations, bflags)
         if ctx.head_major:
             # one re-layout serves both passes: the copy is what gets saved for the backward
@@ -170,20 +200,21 @@ class MultiScaleFlashAttnFunction(torch.autograd.Function):
             # the caller made the per-head copy: only the packed-points kernels take it
             ctx.direct, ctx.head_major = True, True
             fflags |= _lib.FLAG_VALUE_HEAD_MAJOR
-            ctx.bwd_flags = _lib.FLAG_VALUE_HEAD_MAJOR | (
-                _lib.FLAG_TILE_1D if os.environ.get("MSDA_TILE_1D") == "1" else 0
-            )
+            ctx.bwd_flags = fused_route_flags()
             out = _ops.ms_flash_attn_fwd(value, spatial_shapes, level_start_index, packed, fflags)
             ctx.save_for_backward(value, spatial_shapes, level_start_index, packed)
             return out
-        bflags = backward_flags(value, loc)
+        bflags = backward_flags(value, loc, any(ctx.needs_input_grad))
+        ctx.head_major = use_head_major(value, loc, bflags)
+        # the kernels read the packed tensor in place; the reproducible backward does so only on
+        # its binned path (the shapes that also take the per-head copy)
         ctx.direct = (
             os.environ.get("MSDA_NO_PACKED_POINTS") != "1"
-            and not (fflags | bflags) & (_lib.FLAG_GENERIC | _lib.FLAG_DETERMINISTIC)
+            and not (fflags | bflags) & _lib.FLAG_GENERIC
+            and (not bflags & _lib.FLAG_DETERMINISTIC or _ops.head_major_supported(value, loc))
             and value.is_cuda
             and _ops.packed_points_supported(value, packed, levels)
         )
-        ctx.head_major = use_head_major(value, loc, bflags)
         if ctx.head_major:
             value = _ops.ms_deform_attn_value_head_major(value)
             fflags |= _lib.FLAG_VALUE_HEAD_MAJOR
@@ -234,7 +265,7 @@ class MultiScaleRawPointsAttnFunction(torch.autograd.Function):
             value_hm, spatial_shapes, level_start_index, raw, reference_points, flags
         )
         ctx.save_for_backward(value_hm, spatial_shapes, level_start_index, raw, reference_points)
-        ctx.bwd_flags = flags | (_lib.FLAG_TILE_1D if os.environ.get("MSDA_TILE_1D") == "1" else 0)
+        ctx.bwd_flags = fused_route_flags()
         ctx.ref_needs_grad = reference_points.requires_grad
         return out
 

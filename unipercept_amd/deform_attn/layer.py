@@ -14,8 +14,10 @@ import os
 import torch
 from torch import nn
 
+from .. import _lib
 from . import _ops
 from ._function import (
+    route_flags,
     HeadMajorValueFunction,
     MultiScaleRawPointsAttnFunction,
     MultiScaleDeformAttnFunction,
@@ -198,6 +200,10 @@ class MSDeformAttn(nn.Module):
             return False
         if not query.is_cuda or reference_points.shape[-1] != 2:
             return False
+        # kernels forced through the environment (generic, atomic scatter) exist only behind the
+        # unfused op, which honours them
+        if route_flags() & (_lib.FLAG_GENERIC | _lib.FLAG_ATOMIC_SCATTER):
+            return False
         n, lq, _ = query.shape
         width = 3 * self.n_levels * self.n_points
         # the packed locations+weights are fp32 (see forward), whatever the activations' type
@@ -217,6 +223,9 @@ class MSDeformAttn(nn.Module):
         value = self.project_value(input_flatten, None if fuse_mask else input_padding_mask)
         if self.can_fuse_points(query, reference_points, value):
             n, lq, _ = query.shape
+            _lib.check(
+                _lib.load().msda_check_im2col_step(int(n), int(self.im2col_step)), "im2col_step check"
+            )
             weight, bias = self.fused_projection()
             raw = token_linear(query, weight, bias).view(n, lq, self.n_heads, -1)
             # fp32 reference points make the packed locations and weights fp32 even when the

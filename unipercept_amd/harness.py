@@ -12,9 +12,6 @@ from __future__ import annotations
 import dataclasses
 import math
 import os
-import socket
-import subprocess
-import sys
 
 import torch
 
@@ -232,66 +229,7 @@ class FlatGradBucket:
         return dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
 
 
-def launch_ranks(script: str, argv: list[str], nproc: int, *, env: dict | None = None,
-                 timeout: float | None = None) -> int:
-    """Starts `nproc` copies of `python script *argv`, one rank per process (RANK, LOCAL_RANK,
-    WORLD_SIZE, MASTER_ADDR, MASTER_PORT in their environment, as torch.distributed.run sets
-    them), waits for all of them and returns 0 when every rank exited with 0, else the first
-    non-zero exit code (the other ranks are then terminated).  The children inherit stdout and
-    stderr, so whatever rank 0 prints is the launcher's own output.
-
-    The parent must not have touched the GPU: it only starts children and waits (the one-process-
-    per-GPU model of the reference's DDP runs, sources/unipercept/engine/_engine.py:848)."""
-    with socket.socket() as sock:
-        sock.bind(("127.0.0.1", 0))
-        port = sock.getsockname()[1]
-    base = dict(os.environ if env is None else env)
-    base.update(
-        WORLD_SIZE=str(nproc), LOCAL_WORLD_SIZE=str(nproc), MASTER_ADDR="127.0.0.1",
-        MASTER_PORT=str(port),
-    )
-    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    procs = []
-    for r in range(nproc):
-        e = dict(base, RANK=str(r), LOCAL_RANK=str(r))
-        procs.append(subprocess.Popen([sys.executable, script, *argv], env=e))
-    rc = 0
-    try:
-        pending = set(range(nproc))
-        deadline = None if timeout is None else (time_now() + timeout)
-        while pending:
-            for r in sorted(pending):
-                code = procs[r].poll()
-                if code is None:
-                    continue
-                pending.discard(r)
-                if code != 0 and rc == 0:
-                    rc = code
-            if rc != 0 or (deadline is not None and time_now() > deadline):
-                if rc == 0:
-                    rc = 124
-                break
-            if pending:
-                try:
-                    procs[min(pending)].wait(timeout=0.2)
-                except subprocess.TimeoutExpired:
-                    pass
-    finally:
-        for pr in procs:
-            if pr.poll() is None:
-                pr.terminate()
-        for pr in procs:
-            try:
-                pr.wait(timeout=10)
-            except subprocess.TimeoutExpired:
-                pr.kill()
-    return rc
-
-
-def time_now() -> float:
-    import time
-
-    return time.monotonic()
+from .launch import launch_ranks  # noqa: E402,F401  (torch-free; re-exported for callers of the harness)
 
 
 def roofline_fraction(bytes_moved: float, seconds: float, peak_bytes_per_s: float = 8.0e12) -> float:
