@@ -54,9 +54,13 @@ enum {
 
 /* flags for msda_backward */
 enum {
-  /* Compute grad_value without atomics, by a per-destination gather in a fixed order: bitwise
-   * reproducible, O(S * Lq * P) per head and channel — meant for small problems (gradcheck,
-   * debugging), not for throughput. */
+  /* Bitwise reproducible grad_value: two calls on the same inputs give identical bits (grad_loc
+   * and grad_attn always do).  Shapes the binned path covers (msda_head_major_supported) keep
+   * that path and run a tile kernel that adds every position's contributions in an order fixed
+   * by the data (runs in query-block order, rounds made of whole runs, entries sorted per
+   * position): about twice that kernel's time at any size, same workspace.  Other shapes (F64,
+   * head dims without a tuned kernel) use a per-destination gather in a fixed order, O(S * Lq * P)
+   * per head and channel — for small problems (gradcheck, debugging) only. */
   MSDA_FLAG_DETERMINISTIC = 1,
   /* Force the generic (any D, one lane per channel) kernels even where a tuned path exists. */
   MSDA_FLAG_GENERIC = 2,
@@ -94,6 +98,19 @@ enum {
    * (tests/unipercept/nn/layers/test_nn_layers_deform_attn.py:105-122) and is served without
    * this flag.  Where msda_raw_points_supported() says so; `attn` / `grad_attn` are ignored. */
   MSDA_FLAG_RAW_POINTS = 64,
+  /* msda_backward in two calls, for callers that want the binning pass of the binned path out of
+   * the backward (e.g. issued right behind the forward of a training step) and for measuring
+   * what it costs (tools/exp_fwdbin.py).  MSDA_FLAG_BIN_ONLY: only the tile directory and the
+   * scatter records are written into `workspace`; no gradient is written (the gradient pointers
+   * must still be valid).  MSDA_FLAG_BINNED: `workspace` already holds them — from a
+   * MSDA_FLAG_BIN_ONLY call with the same points, shapes, `shapes_host` and layout flags — and
+   * only the gradients are computed.  Both need the binned path in its register-resident form
+   * (tuned shapes, L*P <= 32; MSDA_ELAYOUT otherwise).  Measured on MI355X at the Cityscapes
+   * shapes: the backward gets 0.13 ms shorter (2.32 -> 2.19 ms) and the separate pass costs
+   * 0.30 ms, so one call is the faster way; the kernels never read outside `workspace` or the
+   * tensors whatever the workspace holds. */
+  MSDA_FLAG_BINNED = 128,
+  MSDA_FLAG_BIN_ONLY = 256,
 };
 
 /* Library ABI version (bumped when a signature changes or entry points are added). */
@@ -143,7 +160,7 @@ int msda_packed_points_supported(int N, int S, int M, int D, int Lq, int L, int 
 
 /*
  * 1 when msda_forward and msda_backward take MSDA_FLAG_RAW_POINTS for this problem (tuned
- * kernels, even L*P <= 16, binned backward), else 0; callers then run msda_points_forward /
+ * kernels, even L*P <= 32, binned backward), else 0; callers then run msda_points_forward /
  * msda_points_backward around the packed-points form.  `dtype_loc` is the raw tensor's type.
  */
 int msda_raw_points_supported(int N, int S, int M, int D, int Lq, int L, int P, int dtype_val,
@@ -203,8 +220,10 @@ int msda_backward(const void* grad_out, const void* value, const int64_t* shapes
  * in the reference.  Same arguments and results as msda_backward without the workspace pair: the
  * scratch (directory, scatter records, per-head grad_out copy, or the fp32 accumulation image
  * of the atomic paths) lives in a static 128 MiB device array inside the library, one copy per
- * GPU the library runs on, held until the process ends.  The call itself allocates and frees
- * nothing (no hipMalloc / hipFree, no allocating library routine).
+ * GPU, reserved on every GPU of a process that loads the library (whether or not this entry
+ * point is ever called) and held until the process ends.  The array used is that of the GPU
+ * `hip_stream` belongs to (the current GPU for the default stream).  The call itself allocates
+ * and frees nothing (no hipMalloc / hipFree, no allocating library routine).
  *
  * Limit: msda_backward_workspace_bytes(...) for the problem must be <= 128 MiB (134 217 728
  * bytes), else MSDA_ENOALLOC is returned and nothing is launched; the backward of the

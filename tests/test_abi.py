@@ -45,6 +45,8 @@ def test_enum_values_match_header():
     assert int(enums["MSDA_FLAG_DETERMINISTIC"]) == _lib.FLAG_DETERMINISTIC
     assert int(enums["MSDA_FLAG_GENERIC"]) == _lib.FLAG_GENERIC
     assert int(enums["MSDA_FLAG_ATOMIC_SCATTER"]) == _lib.FLAG_ATOMIC_SCATTER
+    for name in ("VALUE_HEAD_MAJOR", "PACKED_POINTS", "TILE_1D", "RAW_POINTS", "BINNED", "BIN_ONLY"):
+        assert int(enums[f"MSDA_FLAG_{name}"]) == getattr(_lib, f"FLAG_{name}")
 
 
 @pytest.mark.parametrize(
@@ -198,14 +200,15 @@ def test_raw_points_flag_validation():
     ok = lib.msda_raw_points_supported
     assert ok(8, 43008, 8, 32, 43008, 3, 4, _lib.F32, _lib.F32) == 1
     assert ok(16, 21760, 8, 32, 21760, 4, 4, _lib.BF16, _lib.BF16) == 1
-    assert ok(8, 43520, 8, 32, 43520, 4, 8, _lib.F32, _lib.F32) == 0  # 32 points per query
+    assert ok(8, 43520, 8, 32, 43520, 4, 8, _lib.F32, _lib.F32) == 1  # 32 points: two half rows
+    assert ok(8, 43520, 8, 32, 43520, 4, 16, _lib.F32, _lib.F32) == 0  # 64 points per query
     assert ok(1, 630, 5, 16, 515, 3, 3, _lib.F32, _lib.F32) == 0  # odd L*P
     assert ok(1, 640, 2, 30, 5, 2, 2, _lib.F32, _lib.F32) == 0  # no tuned kernel
     raw = _lib.FLAG_RAW_POINTS
     big = (8, 43008, 8, 32, 43008, 3, 4)
     assert _fwd(dims=big, flags=raw, attn=None, ref=None) == -1
     assert _fwd(dims=big, flags=raw, attn=None, ref=FAKE + 4) == -4
-    assert _fwd(dims=(8, 43520, 8, 32, 43520, 4, 8), flags=raw, attn=None, ref=FAKE) == -8
+    assert _fwd(dims=(8, 43520, 8, 32, 43520, 4, 16), flags=raw, attn=None, ref=FAKE) == -8
     assert _bwd(dims=big, dv=0, dl=0, flags=raw, attn=None, grad_attn=None, ref=None) == -1
     assert _bwd(dims=big, dv=0, dl=0, flags=raw | _lib.FLAG_ATOMIC_SCATTER, attn=None, grad_attn=None, ref=FAKE) == -8
 

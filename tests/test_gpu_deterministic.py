@@ -166,3 +166,47 @@ def test_layer_honours_route_switches(mode, monkeypatch):
     assert (out1 - base_out).abs().max() <= 1e-4 * base_out.abs().max()
     for x, y in zip(g1, base_grads):
         assert (x - y).abs().max() <= 1e-4 * max(y.abs().max().item(), 1e-6)
+
+
+def test_binning_as_a_separate_call():
+    """MSDA_FLAG_BIN_ONLY then MSDA_FLAG_BINNED on one workspace, through the C ABI, against the
+    one-call backward: same grad_loc / grad_attn bits, grad_value equal up to the order of its
+    fp32 adds; the binning call writes no gradient."""
+    import ctypes
+
+    lib = _lib.load()
+    w = harness.WORKLOADS["cityscapes_1024x2048_fp32_b8"]
+    value, shapes, lsi, loc, attn, g = harness.synth_inputs(
+        w, "cuda", batch=2, seed=23, dist="R", oob_fraction=0.01
+    )
+    n, s, m, d = value.shape
+    lq, l, p = loc.shape[1], loc.shape[3], loc.shape[4]
+    host = (ctypes.c_int64 * (2 * l))(*[int(x) for x in shapes.flatten().tolist()])
+    st = torch.cuda.current_stream().cuda_stream
+    need = lib.msda_backward_workspace_bytes(n, s, m, d, lq, l, p, 0, 0, 0, host)
+    ws = torch.empty(need, dtype=torch.uint8, device="cuda")
+
+    def call(flags, outs):
+        gv, gl, ga = outs
+        rc = lib.msda_backward(
+            g.data_ptr(), value.data_ptr(), shapes.data_ptr(), lsi.data_ptr(), loc.data_ptr(),
+            attn.data_ptr(), None, gv.data_ptr(), gl.data_ptr(), ga.data_ptr(), ws.data_ptr(), need,
+            n, s, m, d, lq, l, p, 0, 0, flags, host, st,
+        )
+        return rc
+
+    fresh = lambda: (torch.full_like(value, 7.0), torch.full_like(loc, 7.0), torch.full_like(attn, 7.0))
+    want = fresh()
+    assert call(0, want) == 0
+    ws.zero_()
+    untouched = fresh()
+    assert call(_lib.FLAG_BIN_ONLY, untouched) == 0
+    torch.cuda.synchronize()
+    assert all(bool((t == 7.0).all()) for t in untouched)
+    got = fresh()
+    assert call(_lib.FLAG_BINNED, got) == 0
+    assert torch.equal(got[1], want[1]) and torch.equal(got[2], want[2])
+    assert (got[0] - want[0]).abs().max() <= 1e-5 * want[0].abs().max()
+    # the two flags together, or with a path that does not bin, are refused
+    assert call(_lib.FLAG_BINNED | _lib.FLAG_BIN_ONLY, got) == -8
+    assert call(_lib.FLAG_BINNED | _lib.FLAG_GENERIC, got) == -8

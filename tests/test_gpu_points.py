@@ -146,7 +146,10 @@ def test_fused_layer_matches_unfused(route, monkeypatch):
 
 
 RAW_CASES = {
-    # name: (n, lq, m, d, levels, p): all take MSDA_FLAG_RAW_POINTS (tuned head dim, even L*P <= 16)
+    # name: (n, lq, m, d, levels, p): all take MSDA_FLAG_RAW_POINTS (tuned head dim, even L*P <= 32;
+    # rows of more than 16 points run as two half rows per query)
+    "enc_L4P8": (1, None, 8, 32, [(32, 32), (16, 16), (8, 8), (4, 4)], 8),
+    "dec_q301_L3P8": (2, 301, 4, 32, [(32, 64), (16, 32), (8, 16)], 8),
     "enc_L3P4": (2, None, 8, 32, [(32, 64), (16, 32), (8, 16)], 4),
     "enc_L4P4": (1, None, 8, 32, [(32, 32), (16, 16), (8, 8), (4, 4)], 4),
     "dec_q301": (2, 301, 8, 32, [(32, 64), (16, 32), (8, 16)], 4),

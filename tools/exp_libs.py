@@ -71,8 +71,8 @@ ref = None
 for spec, lib in libs.items():
     set_env(spec, True); run(lib, "all"); set_env(spec, False)
     torch.cuda.synchronize()
-    if ref is None: ref = gv.clone()
-    else: print(f"{spec}: grad_value max |diff| vs first variant {(gv - ref).abs().max().item():.3e}", flush=True)
+    if ref is None: ref = (gv.clone(), gl.clone(), ga.clone(), out.clone())
+    else: print(f"{spec}: max |diff| vs first variant: grad_value {(gv - ref[0]).abs().max().item():.3e} grad_loc {(gl - ref[1]).abs().max().item():.3e} grad_attn {(ga - ref[2]).abs().max().item():.3e} out {(out - ref[3]).abs().max().item():.3e}", flush=True)
 for rnd in range(3):
     for spec, lib in libs.items():
         set_env(spec, True)

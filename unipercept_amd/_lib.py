@@ -21,6 +21,8 @@ FLAG_VALUE_HEAD_MAJOR = 8
 FLAG_PACKED_POINTS = 16
 FLAG_TILE_1D = 32
 FLAG_RAW_POINTS = 64
+FLAG_BINNED = 128
+FLAG_BIN_ONLY = 256
 SAMPLE_BILINEAR, SAMPLE_NEAREST = 0, 1
 
 # every symbol include/msda.h declares

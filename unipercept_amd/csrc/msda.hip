@@ -400,6 +400,12 @@ int backward_impl(const void* grad_out, const void* value, const int64_t* shapes
   const Dims d{N, S, M, D, Lq, L, P};
   hipStream_t stream = static_cast<hipStream_t>(hip_stream);
   const bool det = (flags & MSDA_FLAG_DETERMINISTIC) != 0;
+  // the two halves of the binned backward as separate calls
+  const bool binned_given = (flags & MSDA_FLAG_BINNED) != 0, bin_only = (flags & MSDA_FLAG_BIN_ONLY) != 0;
+  if (binned_given && bin_only) return MSDA_ELAYOUT;
+  const int phase = binned_given ? kPhaseGrad : bin_only ? kPhaseBin : (kPhaseBin | kPhaseGrad);
+  if (phase != (kPhaseBin | kPhaseGrad) && (flags & (MSDA_FLAG_GENERIC | MSDA_FLAG_ATOMIC_SCATTER)))
+    return MSDA_ELAYOUT;
 
   // MSDA_FLAG_DETERMINISTIC: the binned path with its reproducible tile kernel where the shape
   // has one (ignoring MSDA_FLAG_ATOMIC_SCATTER), else the generic per-destination gather
@@ -410,10 +416,11 @@ int backward_impl(const void* grad_out, const void* value, const int64_t* shapes
                                  (flags & MSDA_FLAG_VALUE_HEAD_MAJOR) != 0, packed,
                                  (flags & MSDA_FLAG_TILE_1D) ? nullptr : shapes_host,
                                  raw ? static_cast<const float*>(ref_points) : nullptr,
-                                 (flags & 128) ? kPhaseGrad : (flags & 256) ? kPhaseBin : (kPhaseBin | kPhaseGrad), det, stream);
+                                 phase, det, stream);
     if (t != kNotTuned) return t;
   }
-  if ((flags & MSDA_FLAG_VALUE_HEAD_MAJOR) || packed) return MSDA_ELAYOUT;
+  if ((flags & MSDA_FLAG_VALUE_HEAD_MAJOR) || packed || phase != (kPhaseBin | kPhaseGrad))
+    return MSDA_ELAYOUT;
 #define MSDA_BWD(VT, LT, GT)                                                                  \
   bwd_generic<VT, LT, GT>(grad_out, value, shapes_dev, lsi_dev, loc, attn, grad_value,        \
                           grad_loc, grad_attn, workspace, d, det, stream)

@@ -82,6 +82,13 @@ __device__ __forceinline__ unsigned long long stamp_now() {
 #define MSDA_G_COPY 1
 #endif
 
+// Experiment builds only (-DMSDA_EXP_MIN=1): compile the tuned kernels for fp32 rows of 8 chunks
+// (the headline shapes) alone, which cuts the build time of an A/B variant to a fraction; every
+// other type or head dim then reports "not tuned".  Never defined in the shipped library.
+#ifndef MSDA_EXP_MIN
+#define MSDA_EXP_MIN 0
+#endif
+
 constexpr int kNotTuned = INT32_MIN;
 constexpr int MSDA_TUNED_ELAYOUT = -8;  // = MSDA_ELAYOUT of the public header
 constexpr int kMaxLevelsTuned = 16;
@@ -252,7 +259,8 @@ struct BinPlan {
   int tw_shift;     // tile2d: log2 of the patch width (the height is TS / width)
   int in_order;     // always 1; a run-time value on purpose, see the value gather of bwd_query_kernel
   int phase;        // query kernel: bit 0 = bin the scatter (directory + records), bit 1 = gradients
-  int q_per_block;  // queries whose records one region holds (= qb)
+  int q_per_block;  // (real) queries whose records one region holds: qb / split
+  int split;        // virtual queries per query in the query kernel (rows of 17-32 points: 2)
 };
 constexpr int kPhaseBin = 1, kPhaseGrad = 2;
 
@@ -709,7 +717,12 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t* data, int n, 
 // registers: the tensors are read once instead of twice, and the nine dependent global round
 // trips per thread of the count pass plus three per staging pass (each waits behind the gathers
 // of the other workgroups of the CU) become one.
-template <typename VT, typename LT, int G, int MODE, int KPC = 0, int QB = 192>
+// SPLIT (KPC > 0): rows of more than 16 points are taken as SPLIT "virtual" queries of L*P / SPLIT
+// points each — point i of virtual query v of real query q is point (v % SPLIT) * (L*P / SPLIT) + i
+// of q — so that 32 points per query (4 levels x 8 points) run this form too: QB counts virtual
+// queries, a workgroup owns QB / SPLIT real ones (plan.q_per_block), records carry the real
+// query index, and the two halves of a row sit in neighbouring lane groups of one wave.
+template <typename VT, typename LT, int G, int MODE, int KPC = 0, int QB = 192, int SPLIT = 1>
 __global__ __launch_bounds__(256, MSDA_K3_MINWAVES) void bwd_query_kernel(
     const VT* __restrict__ grad_out, const VT* __restrict__ value,
     const int64_t* __restrict__ shapes, const int64_t* __restrict__ lsi,
@@ -727,20 +740,24 @@ __global__ __launch_bounds__(256, MSDA_K3_MINWAVES) void bwd_query_kernel(
   constexpr int NCHUNK = QB / GPB;                         // KPC > 0: chunks of GPB queries per workgroup
   constexpr int PRE = KPC > 0 ? NCHUNK * KPC : 1;      // points a thread keeps in registers
   static_assert(KPC == 0 || MODE == 1, "register-resident points: binned mode only");
+  static_assert(SPLIT == 1 || (KPC > 0 && (SPLIT == 2 || SPLIT == 4) && GQ * SPLIT <= 16),
+                "virtual queries: register-resident form, halves or quarters of a row");
   extern __shared__ uint4 lds[];
   __shared__ LevelInfo lv[kMaxLevelsTuned];
   __shared__ TileMap tm;
   __shared__ uint32_t scan_tmp[4];
 
   const int LP = L * P;
+  const int LPH = LP / SPLIT;  // points per (virtual) query
   const int b = blockIdx.y;
   const int m = blockIdx.x % M;
   const int qblock = blockIdx.x / M;
-  const int qb0 = qblock * plan.qb;
-  const int qb_n = min(plan.qb, Lq - qb0);
+  const int qb0 = qblock * plan.q_per_block;              // first (real) query of the workgroup
+  const int qb_n = min(plan.q_per_block, Lq - qb0);       // its real queries
+  const int vq_n = qb_n * SPLIT;                          // its virtual queries
   MSDA_STAMP_DECL;
   // raw points (KPC > 0 only; the host refuses them elsewhere): softmax statistics of the rows
-  __shared__ float2 row_stats[KPC > 0 ? QB : 1];
+  __shared__ float2 row_stats[KPC > 0 ? QB / SPLIT : 1];
   const bool raw = KPC > 0 && ref != nullptr;
   if (threadIdx.x < L) lv[threadIdx.x] = load_level(shapes, lsi, threadIdx.x, S);
   if constexpr (KPC > 0) {
@@ -770,10 +787,13 @@ __global__ __launch_bounds__(256, MSDA_K3_MINWAVES) void bwd_query_kernel(
   // px / py / pa hold location and weight of point j of chunk c at [c * KPC + j].
   float px[PRE], py[PRE], pa[PRE];
   uint32_t pdesc[PRE];  // per point: record mask and destination tiles, count pass -> emit pass
-  const float inv_LP = 1.0f / static_cast<float>(LP), inv_P = 1.0f / static_cast<float>(P);
-  const auto point_of = [&](int j, int& q, int& i, int& l) {
+  const float inv_LPH = 1.0f / static_cast<float>(LPH), inv_P = 1.0f / static_cast<float>(P);
+  // point j of a chunk: virtual query q of the chunk, slot ih of its LPH points, which is point i
+  // (level l) of the real query
+  const auto point_of = [&](int j, int& q, int& ih, int& i, int& l) {
     int p_unused;
-    small_divmod(static_cast<int>(threadIdx.x) + 256 * j, LP, inv_LP, q, i);
+    small_divmod(static_cast<int>(threadIdx.x) + 256 * j, LPH, inv_LPH, q, ih);
+    i = SPLIT == 1 ? ih : __mul24(q % SPLIT, LPH) + ih;
     small_divmod(i, P, inv_P, l, p_unused);
   };
   // pending chunks' points, parked in LDS while a chunk is gathered: [(c - 1) * KPC + j][x, y, a][thread]
@@ -790,11 +810,11 @@ __global__ __launch_bounds__(256, MSDA_K3_MINWAVES) void bwd_query_kernel(
       for (int j = 0; j < KPC; ++j) {
         // every load is issued (from a clamped, valid row) and the result dropped afterwards when
         // the point does not exist: a branch around a load would make each one wait for the last
-        int q, i, l;
-        point_of(j, q, i, l);
+        int q, ih, i, l;
+        point_of(j, q, ih, i, l);
         const int qi = c * GPB + q;
-        const bool have = q < GPB && qi < qb_n;
-        const uint32_t qc = have ? qi : 0;
+        const bool have = q < GPB && qi < vq_n;
+        const uint32_t qc = have ? static_cast<uint32_t>(qi) / SPLIT : 0;  // real query of the block
         float x, y, a;
         load_point_near(loc_wg, attn_wg, __umul24(qc, M), i, rs, x, y, a);
         if (raw) raw_to_point(ref_wg + (__umul24(qc, L) + l) * 2u, lv[l], row_stats[qc], x, y, a);
@@ -817,8 +837,8 @@ __global__ __launch_bounds__(256, MSDA_K3_MINWAVES) void bwd_query_kernel(
     if constexpr (KPC > 0) {
 #pragma unroll
       for (int k = 0; k < PRE; ++k) {
-        int q, i, l;
-        point_of(k % KPC, q, i, l);
+        int q, ih, i, l;
+        point_of(k % KPC, q, ih, i, l);
         const LevelInfo L_ = lv[l];
         const Footprint<float> f = footprint<float, true>(px[k], py[k], L_.H, L_.W);
         uint32_t desc = 0;
@@ -899,12 +919,13 @@ __global__ __launch_bounds__(256, MSDA_K3_MINWAVES) void bwd_query_kernel(
       for (int k = 0; k < PRE; ++k) {
         const uint32_t desc = pdesc[k];  // from the count pass: no second footprint
         if (desc & 15u) {
-          int q, i, l;
-          point_of(k % KPC, q, i, l);
+          int q, ih, i, l;
+          point_of(k % KPC, q, ih, i, l);
           const uint32_t t0 = (desc >> 4) & 0xfffu, t2 = (desc >> 16) & 0xfffu;
           const uint32_t tiles[4] = {t0, t0 + ((desc >> 28) & 1u), t2, t2 + ((desc >> 29) & 1u)};
           uint4 rec;
-          rec.x = static_cast<uint32_t>(qb0 + (k / KPC) * GPB + q) | (static_cast<uint32_t>(l) << 28);
+          rec.x = static_cast<uint32_t>(qb0 + ((k / KPC) * GPB + q) / SPLIT) |
+                  (static_cast<uint32_t>(l) << 28);
           rec.y = __float_as_uint(pa[k]);
           rec.z = __float_as_uint(px[k]);
           rec.w = __float_as_uint(py[k]);
@@ -940,14 +961,14 @@ __global__ __launch_bounds__(256, MSDA_K3_MINWAVES) void bwd_query_kernel(
         stash[((k - KPC) * 3 + 2) * 256 + threadIdx.x] = pa[k];
       }
       const int stride = group_stride_slots(LPB, SL);
-      const int nq0 = min(GPB, qb_n);
+      const int nq0 = min(GPB, vq_n);
 #pragma unroll
       for (int j = 0; j < KPC; ++j) {
-        int q, i, l;
-        point_of(j, q, i, l);
+        int q, ih, i, l;
+        point_of(j, q, ih, i, l);
         if (q < nq0)
-          stage_point<KIND, false>(lv[l], l, px[j], py[j], pa[j], qb0 + q,
-                                   stage + (__umul24(q, stride) + SL * i), rowb, headb, emit, raw);
+          stage_point<KIND, false>(lv[l], l, px[j], py[j], pa[j], qb0 + q / SPLIT,
+                                   stage + (__umul24(q, stride) + SL * ih), rowb, headb, emit, raw);
       }
     }
   }
@@ -959,10 +980,11 @@ __global__ __launch_bounds__(256, MSDA_K3_MINWAVES) void bwd_query_kernel(
 
   // chunks of GPB queries; inside a chunk the points are staged LPB at a time (LPB is a multiple
   // of G, and all of L*P for the usual sizes)
-  for (int c0 = 0; c0 < qb_n; c0 += GPB)
-  for (int ib = 0; ib < LP; ib += LPB) {
-    const int nq = min(GPB, qb_n - c0);
-    const int nI = min(LPB, LP - ib);
+  // (virtual queries, LPH points each: the real ones with all L*P points unless SPLIT > 1)
+  for (int c0 = 0; c0 < vq_n; c0 += GPB)
+  for (int ib = 0; ib < LPH; ib += LPB) {
+    const int nq = min(GPB, vq_n - c0);
+    const int nI = min(LPB, LPH - ib);
     if constexpr (KPC > 0) {
       // staged already: the first chunk by the prologue, the others behind the previous gather
     } else {
@@ -976,7 +998,9 @@ __global__ __launch_bounds__(256, MSDA_K3_MINWAVES) void bwd_query_kernel(
     const bool live = g < nq;
     const int gg = live ? g : nq - 1;
     const uint4* r = stage + __umul24(gg, group_stride_slots(LPB, SL));
-    const int64_t triple = (static_cast<int64_t>(b) * Lq + qb0 + c0 + gg) * M + m;
+    const int rq = qb0 + (c0 + gg) / SPLIT;      // the real query of this group
+    const int half_i = ((c0 + gg) % SPLIT) * LPH;  // first point of the group's part of its row
+    const int64_t triple = (static_cast<int64_t>(b) * Lq + rq) * M + m;
     float go[NC][CPL];
     uint4 go_raw[NC];  // the same chunks as loaded (16-bit types: still packed)
 #pragma unroll
@@ -985,9 +1009,9 @@ __global__ __launch_bounds__(256, MSDA_K3_MINWAVES) void bwd_query_kernel(
                                                   triple * D * sizeof(VT) + (lane + j * GQ) * 16);
       Chunk<VT>::unpack(go_raw[j], go[j]);
     }
-    if (g_copy != nullptr && ib == 0 && live) {
+    if (g_copy != nullptr && ib == 0 && live && half_i == 0) {
       // the row again, where the tile kernel will look for it: (batch, head, query) order
-      const int64_t hm_row = (static_cast<int64_t>(b) * M + m) * Lq + qb0 + c0 + gg;
+      const int64_t hm_row = (static_cast<int64_t>(b) * M + m) * Lq + rq;
 #pragma unroll
       for (int j = 0; j < NC; ++j)
         *reinterpret_cast<uint4*>(reinterpret_cast<char*>(g_copy) + hm_row * D * sizeof(VT) +
@@ -1087,8 +1111,8 @@ __global__ __launch_bounds__(256, MSDA_K3_MINWAVES) void bwd_query_kernel(
             }
         }
         if (lane < PP && i < nI && live && !(kAblate & 2)) {
-          if (!raw) Elem<LT>::store(grad_attn + triple * rs.attn + ib + i, keep_sv);
-          LT* gl = grad_loc + triple * rs.loc + 2 * (ib + i);
+          if (!raw) Elem<LT>::store(grad_attn + triple * rs.attn + half_i + ib + i, keep_sv);
+          LT* gl = grad_loc + triple * rs.loc + 2 * (half_i + ib + i);
           if constexpr (sizeof(LT) == 4) {
             *reinterpret_cast<float2*>(gl) = make_float2(keep_sx, keep_sy);
           } else {
@@ -1101,12 +1125,13 @@ __global__ __launch_bounds__(256, MSDA_K3_MINWAVES) void bwd_query_kernel(
         float part = 0.f;
 #pragma unroll
         for (int ps = 0; ps < 4; ++ps) part = fmaf(ka[ps], kg[ps], part);
-        const float dot_wg = group_sum<GQ>(part);  // sum_k w_k g_k of the query
+        // sum_k w_k g_k over the whole row: the lane groups of its SPLIT parts are neighbours
+        const float dot_wg = group_sum<GQ * SPLIT>(part);
 #pragma unroll
         for (int ps = 0; ps < 4; ++ps) {
           const int i = ps * PP + lane;
           if (lane < PP && i < nI && live && !(kAblate & 2))
-            Elem<LT>::store(grad_attn + triple * rs.attn + ib + i, ka[ps] * (kg[ps] - dot_wg));
+            Elem<LT>::store(grad_attn + triple * rs.attn + half_i + ib + i, ka[ps] * (kg[ps] - dot_wg));
         }
       }
     } else {
@@ -1183,8 +1208,8 @@ __global__ __launch_bounds__(256, MSDA_K3_MINWAVES) void bwd_query_kernel(
       const int i = i0 + lane;
       if (i < nI && live && !(kAblate & 2)) {
         // the gradients have the layout of their inputs (separate tensors or one packed row)
-        Elem<LT>::store(grad_attn + triple * rs.attn + ib + i, keep_sv);
-        LT* gl = grad_loc + triple * rs.loc + 2 * (ib + i);
+        Elem<LT>::store(grad_attn + triple * rs.attn + half_i + ib + i, keep_sv);
+        LT* gl = grad_loc + triple * rs.loc + 2 * (half_i + ib + i);
         if constexpr (sizeof(LT) == 4) {
           *reinterpret_cast<float2*>(gl) = make_float2(keep_sx, keep_sy);
         } else {
@@ -1200,19 +1225,19 @@ __global__ __launch_bounds__(256, MSDA_K3_MINWAVES) void bwd_query_kernel(
     if constexpr (KPC > 0) {
       // the next chunk's points come back from where this thread parked them
       const int cn = c0 / GPB + 1;
-      const int nqn = min(GPB, qb_n - cn * GPB);
+      const int nqn = min(GPB, vq_n - cn * GPB);
       if (nqn > 0) {
         const int stride = group_stride_slots(LPB, SL);
 #pragma unroll
         for (int j = 0; j < KPC; ++j) {
-          int q, i, l;
-          point_of(j, q, i, l);
+          int q, ih, i, l;
+          point_of(j, q, ih, i, l);
           const float x = stash[(((cn - 1) * KPC + j) * 3 + 0) * 256 + threadIdx.x];
           const float y = stash[(((cn - 1) * KPC + j) * 3 + 1) * 256 + threadIdx.x];
           const float a = stash[(((cn - 1) * KPC + j) * 3 + 2) * 256 + threadIdx.x];
           if (q < nqn)
-            stage_point<KIND, false>(lv[l], l, x, y, a, qb0 + cn * GPB + q,
-                                     stage + (__umul24(q, stride) + SL * i), rowb, headb, emit, raw);
+            stage_point<KIND, false>(lv[l], l, x, y, a, qb0 + (cn * GPB + q) / SPLIT,
+                                     stage + (__umul24(q, stride) + SL * ih), rowb, headb, emit, raw);
         }
       }
     }
@@ -1717,6 +1742,11 @@ inline bool all_aligned16(std::initializer_list<const void*> ps) {
 // queries per workgroup make it three, 128 it is (COCO 4 levels x 4 points, bf16: backward
 // 2.44 -> 2.27 ms; with 12 points per query both sizes run three workgroups and 128 is 2 %
 // slower).  G = 16-byte chunks per row, 0 when not known.
+// Rows of 17-32 points (an even number) run the register-resident query kernel as two virtual
+// queries of half a row each.
+inline int row_split(int LP) { return MSDA_K3_PRE && LP > 16 && LP <= 32 && LP % 2 == 0 ? 2 : 1; }
+
+// LP: points per virtual query
 inline int choose_qb(int G, int LP, int64_t n_tiles) {
   if (!MSDA_K3_PRE || G == 0 || LP > 16) return 192;
   const int GQ = query_lanes(G), GPB = 256 / GQ;
@@ -1751,8 +1781,12 @@ inline bool make_bin_plan(int N, int S, int M, int D, int Lq, int L, int P, int 
     }
     if (ok && total == S) nt2d = nt;
   }
-  const int qb = choose_qb(G, L * P, nt2d >= 0 ? nt2d : n_tiles);
-  const int64_t n_qblocks = (static_cast<int64_t>(Lq) + qb - 1) / qb;
+  // virtual queries per workgroup (split rows: always 128, one kernel variant fewer) and the
+  // real queries they stand for
+  const int split = G == 0 ? 1 : row_split(L * P);
+  const int qb = split > 1 ? 128 : choose_qb(G, L * P, nt2d >= 0 ? nt2d : n_tiles);
+  const int qpb = qb / split;
+  const int64_t n_qblocks = (static_cast<int64_t>(Lq) + qpb - 1) / qpb;
   const auto fits = [&](int64_t nt) {
     return nt <= 4096 && slabs * n_qblocks * nt * 8 <= (static_cast<int64_t>(1) << 30) &&
            nt * M <= INT32_MAX;
@@ -1765,7 +1799,7 @@ inline bool make_bin_plan(int N, int S, int M, int D, int Lq, int L, int P, int 
   if (!fits(n_tiles) || n_qblocks > 2048 || Lq >= (1 << 28)) return false;
   const int64_t dir_b = slabs * n_qblocks * n_tiles * 8;
   // a point lands in at most 4 tiles: regions can never overflow
-  const int64_t region = static_cast<int64_t>(qb) * L * P * 4;
+  const int64_t region = static_cast<int64_t>(qpb) * L * P * 4;
   const int64_t rec_b = slabs * n_qblocks * region * 16;
   if (n_qblocks * M > INT32_MAX) return false;
   plan->ts_shift = ts_shift;
@@ -1777,7 +1811,8 @@ inline bool make_bin_plan(int N, int S, int M, int D, int Lq, int L, int P, int 
   plan->tw_shift = tw_shift;
   plan->in_order = 1;
   plan->phase = kPhaseBin | kPhaseGrad;
-  plan->q_per_block = qb;
+  plan->q_per_block = qpb;
+  plan->split = split;
   *dir_bytes = (static_cast<size_t>(dir_b) + 255) & ~static_cast<size_t>(255);
   *rec_bytes = static_cast<size_t>(rec_b);
   return true;
@@ -1803,8 +1838,8 @@ inline bool raw_points_supported(int N, int S, int M, int D, int Lq, int L, int 
   size_t a, b;
   return MSDA_K3_PRE && MSDA_K3_DEPTH == 2 &&
          tuned_shape_ok(N, S, M, D, Lq, L, P, dtype_val, dtype_loc, &G) && packed_shape_ok(L, P) &&
-         L * P <= 16 && make_bin_plan(N, S, M, D, Lq, L, P, G, nullptr, &plan, &a, &b) &&
-         (plan.qb == 192 || plan.qb == 128);
+         make_bin_plan(N, S, M, D, Lq, L, P, G, nullptr, &plan, &a, &b) &&
+         L * P / plan.split <= 16 && (plan.qb == 192 || plan.qb == 128);
 }
 
 // (N,S,M,D) <-> (N,M,S,D): rows of D*e bytes move whole, 16 bytes per lane.  `mask` (n, S) bytes,
@@ -1850,6 +1885,7 @@ int tuned_forward_typed(const void* value, const int64_t* shapes, const int64_t*
                      static_cast<const LT*>(attn), static_cast<VT*>(out), S, M, Lq, L, P, LPB,   \
                      head_major ? 1 : 0, rs, ref)
   switch (G) {
+#if !MSDA_EXP_MIN
     case 4:
       if (pair) {
         MSDA_TF(4, true);
@@ -1857,8 +1893,9 @@ int tuned_forward_typed(const void* value, const int64_t* shapes, const int64_t*
         MSDA_TF(4, false);
       }
       break;
-    case 8: MSDA_TF(8, false); break;
-    default: MSDA_TF(16, false); break;
+    case 16: MSDA_TF(16, false); break;
+#endif
+    default: MSDA_TF(8, false); break;
   }
 #undef MSDA_TF
   return run.rc;
@@ -1870,6 +1907,11 @@ inline int tuned_forward(const void* value, const int64_t* shapes, const int64_t
                          bool packed, const float* ref, hipStream_t stream) {
   int G;
   if (!tuned_shape_ok(N, S, M, D, Lq, L, P, dtype_val, dtype_loc, &G)) return kNotTuned;
+#if MSDA_EXP_MIN
+  if (dtype_val != 0 || G != 8) return kNotTuned;
+  return tuned_forward_typed<float, float>(value, shapes, lsi, loc, attn, out, N, S, M, Lq, L, P, G,
+                                           head_major, packed, ref, stream);
+#else
   if (!all_aligned16({value, out})) return kNotTuned;
   if (!pair_aligned(loc, dtype_loc) || (packed && !packed_shape_ok(L, P))) return kNotTuned;
 #define MSDA_ARGS \
@@ -1881,6 +1923,7 @@ inline int tuned_forward(const void* value, const int64_t* shapes, const int64_t
   return dtype_loc == 0 ? tuned_forward_typed<f16_t, float>(MSDA_ARGS)
                         : tuned_forward_typed<f16_t, f16_t>(MSDA_ARGS);
 #undef MSDA_ARGS
+#endif
 }
 
 // bytes of the per-head grad_out copy at the end of the binned backward's workspace
@@ -1927,9 +1970,10 @@ int tuned_backward_typed(const void* grad_out, const void* value, const int64_t*
   // Register-resident points (see bwd_query_kernel): 4 lanes per query, three chunks of 64
   // queries per workgroup, up to 16 points per query staged in one pass (34 KB of LDS at 16).
   int kpc = 0;
-  if (MSDA_K3_PRE && binned && (plan.qb == 192 || plan.qb == 128) && LP <= 16) {
-    kpc = GQ == 4 ? (LP <= 12 ? 3 : 4) : 2;  // ceil(GPB * LP / 256), rounded up to a built variant
-    LPB = LP;
+  const int LPH = binned ? LP / plan.split : LP;  // points per (virtual) query
+  if (MSDA_K3_PRE && binned && (plan.qb == 192 || plan.qb == 128) && LPH <= 16) {
+    kpc = GQ == 4 ? (LPH <= 12 ? 3 : 4) : 2;  // ceil(GPB * LPH / 256), rounded up to a built variant
+    LPB = LPH;
   }
   Launches run;
   // raw points are handled by the register-resident form of the query kernel only
@@ -1972,18 +2016,34 @@ int tuned_backward_typed(const void* grad_out, const void* value, const int64_t*
       g_copy ? static_cast<const VT*>(g_copy) : static_cast<const VT*>(grad_out), shapes, lsi,   \
       records, dir, static_cast<VT*>(grad_value), S, M, Lq, L, LP, plan, g_copy ? 1 : 0)
 #define MSDA_TQ(GG, KK)                                                                          \
-  if ((KK) > 0 && plan.qb == 128) {                                                              \
-    MSDA_TQB(GG, KK, ((KK) > 0 ? 128 : 192));                                                    \
+  if ((KK) > 0 && plan.split == 2) {                                                             \
+    MSDA_TQB(GG, KK, ((KK) > 0 ? 128 : 192), ((KK) > 0 ? 2 : 1));                                \
+  } else if ((KK) > 0 && plan.qb == 128) {                                                       \
+    MSDA_TQB(GG, KK, ((KK) > 0 ? 128 : 192), 1);                                                 \
   } else {                                                                                       \
-    MSDA_TQB(GG, KK, 192);                                                                       \
+    MSDA_TQB(GG, KK, 192, 1);                                                                    \
   }
-#define MSDA_TQB(GG, KK, QQ)                                                                     \
-  run((bwd_query_kernel<VT, LT, GG, 1, KK, QQ>), qgrid, dim3(256), qlds, stream,  \
+#define MSDA_TQB(GG, KK, QQ, SS)                                                                 \
+  run((bwd_query_kernel<VT, LT, GG, 1, KK, QQ, SS>), qgrid, dim3(256), qlds, stream,             \
                      static_cast<const VT*>(grad_out), static_cast<const VT*>(value), shapes,    \
                      lsi, static_cast<const LT*>(loc), static_cast<const LT*>(attn),             \
                      static_cast<LT*>(grad_loc), static_cast<LT*>(grad_attn),                    \
                      static_cast<float*>(nullptr), records, dir, g_copy, S, M, Lq, L, P, LPB,    \
                      head_major ? 1 : 0, rs, plan, ref)
+#if MSDA_EXP_MIN
+#define MSDA_TB(GG, UU)                                                                          \
+  if (MSDA_EXP_MIN == 2) {                                                                       \
+    if (kpc != 4 || plan.qb != 128 || plan.split != 2) return kNotTuned;                         \
+    MSDA_TQB(GG, 4, 128, 2);                                                                     \
+  } else {                                                                                       \
+    if (kpc != 3 || plan.qb != 192) return kNotTuned;                                            \
+    MSDA_TQB(GG, 3, 192, 1);                                                                     \
+  }                                                                                              \
+  if (phase & kPhaseGrad) {                                                                      \
+    if (det) return kNotTuned;                                                                   \
+    MSDA_TILE(GG, RPT, UU);                                                                      \
+  }
+#else
 #define MSDA_TB(GG, UU)                                                                          \
   if (kpc == 0) {                                                                                \
     MSDA_TQ(GG, 0);                                                                              \
@@ -2003,10 +2063,13 @@ int tuned_backward_typed(const void* grad_out, const void* value, const int64_t*
       MSDA_TILE(GG, RPT, UU);                                                                    \
     }                                                                                            \
   }
+#endif
     switch (G) {
+#if !MSDA_EXP_MIN
       case 4: MSDA_TB(4, 3); break;
-      case 8: MSDA_TB(8, 3); break;
-      default: MSDA_TB(16, 2); break;
+      case 16: MSDA_TB(16, 2); break;
+#endif
+      default: MSDA_TB(8, 3); break;
     }
 #undef MSDA_TB
 #undef MSDA_TQ
@@ -2019,7 +2082,12 @@ int tuned_backward_typed(const void* grad_out, const void* value, const int64_t*
   // fp32-atomic fallback (very long sequences); it indexes grad_value with the value offsets,
   // so it only takes the position-major layout
   if (head_major) return MSDA_TUNED_ELAYOUT;
+#if MSDA_EXP_MIN
+  return kNotTuned;
+#endif
   plan.qb = 256;
+  plan.q_per_block = 256;
+  plan.split = 1;
   plan.n_qblocks = (Lq + plan.qb - 1) / plan.qb;
   plan.n_tiles = 0;
   plan.tile2d = 0;
@@ -2041,9 +2109,11 @@ int tuned_backward_typed(const void* grad_out, const void* value, const int64_t*
                      static_cast<VT*>(nullptr), S, M, Lq, L, P, LPB, 0, rs, plan,                \
                      static_cast<const float*>(nullptr))
   switch (G) {
+#if !MSDA_EXP_MIN
     case 4: MSDA_TB(4); break;
-    case 8: MSDA_TB(8); break;
-    default: MSDA_TB(16); break;
+    case 16: MSDA_TB(16); break;
+#endif
+    default: MSDA_TB(8); break;
   }
 #undef MSDA_TB
   if constexpr (!kDirect) {
@@ -2072,6 +2142,10 @@ inline int tuned_backward(const void* grad_out, const void* value, const int64_t
 #define MSDA_ARGS                                                                               \
   grad_out, value, shapes, lsi, loc, attn, grad_value, grad_loc, grad_attn, workspace, N, S, M, \
       D, Lq, L, P, G, allow_binned, head_major, packed, levels_host, ref, phase, det, stream
+#if MSDA_EXP_MIN
+  if (dtype_val != 0 || G != 8) return kNotTuned;
+  return tuned_backward_typed<float, float>(MSDA_ARGS);
+#endif
   if (dtype_val == 0) return tuned_backward_typed<float, float>(MSDA_ARGS);
   if (dtype_val == 2)
     return dtype_loc == 0 ? tuned_backward_typed<bf16_t, float>(MSDA_ARGS)
