@@ -142,17 +142,26 @@ def test_workspace_bytes():
     assert ws(n, s, m, d, s, l, p, _lib.BF16, _lib.F32, _lib.FLAG_ATOMIC_SCATTER) == n * s * m * d * 4
     # invalid arguments give 0
     assert ws(0, s, m, d, s, l, p, _lib.F32, _lib.F32, 0) == 0
-    # host level shapes select 8x8 patches: same count here (every extent divides by 8) ...
+    # host level shapes select 2-D patches: 7 x 7 (tile kernel by footprint origin) for rows of up
+    # to 32 channels, 8 x 8 for the reproducible backward and for wider rows — the directory grows
+    # with the tile count, nothing else changes
     host = (ctypes.c_int64 * 6)(128, 256, 64, 128, 32, 64)
-    assert ws_h(n, s, m, d, s, l, p, _lib.F32, _lib.F32, 0, host) == ws(n, s, m, d, s, l, p, _lib.F32, _lib.F32, 0)
-    # ... more tiles when the extents are ragged (3 levels of 20x24, 10x12, 5x6: 9+4+1 patches
+    r256 = lambda x: -(-x // 256) * 256
+    tiles7 = 19 * 37 + 10 * 19 + 5 * 10
+    base8 = ws(n, s, m, d, s, l, p, _lib.F32, _lib.F32, 0)  # 672 runs of 64 = as many 8 x 8 patches
+    assert ws_h(n, s, m, d, s, l, p, _lib.F32, _lib.F32, 0, host) - base8 == (
+        r256(n * m * qblocks * tiles7 * 8) - r256(dir_bytes))
+    assert ws_h(n, s, m, d, s, l, p, _lib.F32, _lib.F32, det, host) == base8
+    assert ws_h(n, s, m, 64, s, l, p, _lib.F32, _lib.F32, 0, host) == ws(n, s, m, 64, s, l, p, _lib.F32, _lib.F32, 0)
+    # ragged extents (3 levels of 20x24, 10x12, 5x6: 12+4+1 patches of 7 x 7, 9+4+1 of 8 x 8,
     # against ceil(630/64) = 10 runs), and the 1-D plan when the table does not cover S
     s2 = 20 * 24 + 10 * 12 + 5 * 6
     ragged = (ctypes.c_int64 * 6)(20, 24, 10, 12, 5, 6)
     base = ws(1, s2, m, d, s2, l, p, _lib.F32, _lib.F32, 0)
     qb2 = -(-s2 // 192)
-    r256 = lambda x: -(-x // 256) * 256
     assert (ws_h(1, s2, m, d, s2, l, p, _lib.F32, _lib.F32, 0, ragged) - base
+            == r256(m * qb2 * 17 * 8) - r256(m * qb2 * 10 * 8))
+    assert (ws_h(1, s2, m, d, s2, l, p, _lib.F32, _lib.F32, det, ragged) - base
             == r256(m * qb2 * 14 * 8) - r256(m * qb2 * 10 * 8))
     wrong = (ctypes.c_int64 * 6)(20, 24, 10, 12, 5, 7)
     assert ws_h(1, s2, m, d, s2, l, p, _lib.F32, _lib.F32, 0, wrong) == base
@@ -275,7 +284,7 @@ def test_workspace_reflects_queries_per_workgroup():
     def expect(n, m, d, esize, levels, p, qb):
         s = sum(h * w for h, w in levels)
         lq, l = s, len(levels)
-        tiles = sum(-(-h // 8) * -(-w // 8) for h, w in levels)
+        tiles = sum(-(-h // 7) * -(-w // 7) for h, w in levels)  # 7 x 7 patches (rows of 32 channels)
         blocks = -(-lq // qb)
         dir_b = (n * m * blocks * tiles * 8 + 255) // 256 * 256
         rec_b = n * m * blocks * (qb * l * p * 4) * 16

@@ -106,11 +106,35 @@ struct Footprint {
 
 // SMALL: H * W fits 24 bits (the caller's promise), so the row offsets come from the full-rate
 // 24-bit multiply instead of the quarter-rate 32-bit one.
+// pixel coordinate of a normalised location on an axis of n pixels (align_corners = False); one
+// definition, so that every kernel rounds it the same way
+template <typename CT>
+__device__ __forceinline__ CT pixel_coord(CT loc, int n) {
+  return loc * static_cast<CT>(n) - static_cast<CT>(0.5);
+}
+
+// The part of a footprint the origin tile kernel needs: whether the point lies inside the skirt,
+// the footprint's origin + 1 (oy = y0 + 1 in 0 .. H, ox = x0 + 1 in 0 .. W) and the fractions —
+// the same numbers footprint() derives from the same location.
+__device__ __forceinline__ bool footprint_origin(float locx, float locy, int H, int W, int& oy,
+                                                 int& ox, float& ly, float& lx) {
+  const float x = pixel_coord(locx, W), y = pixel_coord(locy, H);
+  const bool any = (y > -1.f) && (x > -1.f) && (y < static_cast<float>(H)) &&
+                   (x < static_cast<float>(W)) && H > 0 && W > 0;
+  const float xs = any ? x : 0.f, ys = any ? y : 0.f;
+  const float xf = floorf(xs), yf = floorf(ys);
+  lx = xs - xf;
+  ly = ys - yf;
+  ox = static_cast<int>(xf) + 1;
+  oy = static_cast<int>(yf) + 1;
+  return any;
+}
+
 template <typename CT, bool SMALL = false>
 __device__ __forceinline__ Footprint<CT> footprint(CT locx, CT locy, int H, int W) {
   Footprint<CT> f;
-  const CT x = locx * static_cast<CT>(W) - static_cast<CT>(0.5);
-  const CT y = locy * static_cast<CT>(H) - static_cast<CT>(0.5);
+  const CT x = pixel_coord(locx, W);
+  const CT y = pixel_coord(locy, H);
   f.any = (y > static_cast<CT>(-1)) && (x > static_cast<CT>(-1)) && (y < static_cast<CT>(H)) &&
           (x < static_cast<CT>(W)) && H > 0 && W > 0;
   // clamp first so that the float->int conversion below is always defined (NaN/inf/huge inputs)

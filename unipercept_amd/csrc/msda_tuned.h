@@ -241,8 +241,15 @@ __host__ __device__ constexpr int query_lanes(int G) { return (MSDA_K3_WIDE && G
 //   x = query index | level << 28, y = attention weight, z/w = normalised location (x, y) as f32
 constexpr uint32_t kRecInvalid = 0xffffffffu;
 
-constexpr int kTileShift = 6;       // positions per destination tile: 64, one per 4-lane group
-constexpr int kTileWidthShift = 3;  // 2-D tiles are 8 x 8 patches
+constexpr int kTileShift = 6;  // positions per 1-D destination tile: 64, one per 4-lane group
+
+// 2-D tiles are square patches of 8 x 8 pixels, or 7 x 7 where the tile kernel works by footprint
+// origin (bwd_tile_origin_kernel).  v / tw for those two widths without the integer-division
+// sequence; 0 <= v < 13000 for tw = 7 (level extents are bounded on the host), and -1 -> -1.
+__host__ __device__ __forceinline__ int tile_div(int v, int tw) {
+  return tw == 8 ? v >> 3 : (v * 9363) >> 16;
+}
+constexpr int kMaxExtentTile7 = 8192;
 
 // Destination tiles of the binned grad_value scatter.  tile2d = 0: a tile is TS consecutive
 // positions of the flattened (level-concatenated) sequence.  tile2d = 1: a tile is an 8 x 8 pixel
@@ -256,7 +263,7 @@ struct BinPlan {
   int n_qblocks;    // ceil(Lq / qb)
   uint32_t region;  // records per workgroup region
   int tile2d;       // tile geometry (see above)
-  int tw_shift;     // tile2d: log2 of the patch width (the height is TS / width)
+  int tw;           // tile2d: patches are tw x tw pixels (8, or 7 with the origin tile kernel)
   int in_order;     // always 1; a run-time value on purpose, see the value gather of bwd_query_kernel
   int phase;        // query kernel: bit 0 = bin the scatter (directory + records), bit 1 = gradients
   int q_per_block;  // (real) queries whose records one region holds: qb / split
@@ -271,11 +278,10 @@ struct TileMap {  // tile2d only: first tile id and tiles per row of every level
 
 __device__ __forceinline__ void build_tile_map(const LevelInfo* lv, int L, const BinPlan& plan,
                                                TileMap& tm) {
-  const int tw_shift = plan.tw_shift, th_shift = plan.ts_shift - plan.tw_shift;
   int run = 0;
   for (int l = 0; l < L; ++l) {
-    const int tx = (lv[l].W + (1 << tw_shift) - 1) >> tw_shift;
-    const int ty = (lv[l].H + (1 << th_shift) - 1) >> th_shift;
+    const int tx = tile_div(lv[l].W - 1, plan.tw) + 1;
+    const int ty = tile_div(lv[l].H - 1, plan.tw) + 1;
     tm.tstart[l] = run;
     tm.tx[l] = tx;
     run += tx * ty;
@@ -293,8 +299,8 @@ __device__ __forceinline__ void locate_tile(const TileMap& tm, int L, const BinP
   y0 = x0 = 0;
   if (l >= 0) {
     const int r = tile - tm.tstart[l];
-    y0 = (r / tm.tx[l]) << (plan.ts_shift - plan.tw_shift);
-    x0 = (r % tm.tx[l]) << plan.tw_shift;
+    y0 = (r / tm.tx[l]) * plan.tw;
+    x0 = (r % tm.tx[l]) * plan.tw;
   }
 }
 
@@ -303,10 +309,9 @@ __device__ __forceinline__ void pixel_tile(const BinPlan& plan, const TileMap& t
                                            const LevelInfo& L_, int l, int cy, int cx,
                                            uint32_t& tile, uint32_t& local) {
   if (plan.tile2d) {
-    const int tw_shift = plan.tw_shift, th_shift = plan.ts_shift - plan.tw_shift;
-    tile = static_cast<uint32_t>(tm.tstart[l] + __umul24(cy >> th_shift, tm.tx[l]) + (cx >> tw_shift));
-    local = static_cast<uint32_t>(((cy & ((1 << th_shift) - 1)) << tw_shift) |
-                                  (cx & ((1 << tw_shift) - 1)));
+    const int tw = plan.tw, tyi = tile_div(cy, tw), txi = tile_div(cx, tw);
+    tile = static_cast<uint32_t>(tm.tstart[l] + __umul24(tyi, tm.tx[l]) + txi);
+    local = static_cast<uint32_t>(__mul24(cy - __mul24(tyi, tw), tw) + (cx - __mul24(txi, tw)));
   } else {
     const uint32_t pos = static_cast<uint32_t>(L_.start + __umul24(cy, L_.W) + cx);
     tile = pos >> plan.ts_shift;
@@ -325,9 +330,9 @@ __device__ __forceinline__ void footprint_tiles(const Footprint<float>& f, const
     // a patch is a product of a row range and a column range, so rows and columns dedupe
     // separately: the second row (column) adds tiles only if it is inside the level and falls in
     // another patch row (column) than a first one that counts
-    const int tw_shift = plan.tw_shift, th_shift = plan.ts_shift - plan.tw_shift;
-    const int ty0 = f.cy[0] >> th_shift, ty1 = f.cy[1] >> th_shift;
-    const int tx0 = f.cx[0] >> tw_shift, tx1 = f.cx[1] >> tw_shift;
+    const int tw = plan.tw;
+    const int ty0 = tile_div(f.cy[0], tw), ty1 = tile_div(f.cy[1], tw);
+    const int tx0 = tile_div(f.cx[0], tw), tx1 = tile_div(f.cx[1], tw);
     const int txl = tm.tx[l];
     const uint32_t base0 = static_cast<uint32_t>(tm.tstart[l] + __umul24(ty0, txl));
     const uint32_t base1 = static_cast<uint32_t>(tm.tstart[l] + __umul24(ty1, txl));
@@ -1448,8 +1453,10 @@ __global__ __launch_bounds__(256) void bwd_tile_gather_kernel(
   if (plan.tile2d) {
     const int l = tile_level_s;
     if (l < 0) return;
-    const int yy = tile_y0_s + (pg >> plan.tw_shift);
-    const int xx = tile_x0_s + (pg & ((1 << plan.tw_shift) - 1));
+    if (pg >= plan.tw * plan.tw) return;
+    const int row = tile_div(pg, plan.tw);
+    const int yy = tile_y0_s + row;
+    const int xx = tile_x0_s + (pg - row * plan.tw);
     if (yy >= lv[l].H || xx >= lv[l].W) return;
     pos = lv[l].start + static_cast<int64_t>(yy) * lv[l].W + xx;
   } else {
@@ -1460,6 +1467,240 @@ __global__ __launch_bounds__(256) void bwd_tile_gather_kernel(
               (((static_cast<int64_t>(b) * S + pos) * M + m) * D) * sizeof(VT) + pl * 16;
 #pragma unroll
   for (int j = 0; j < NCH; ++j) Chunk<VT>::store(dst + j * PL * 16, sum[j]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Backward, destination side, by footprint origin: one workgroup per (batch, head, 7 x 7 patch)
+//
+// The position kernel above fetches a record's grad_out row once per corner that falls into the
+// tile (3-4 times per record).  Here a record is fetched ONCE: the tile's records are bucketed by
+// the ORIGIN of their footprint (its top-left pixel (y0, x0), y0 = -1 .. H - 1), and the 4 lanes
+// that own an origin slot keep four running sums — one per corner of the 2 x 2 footprint — in
+// registers.  The footprints that touch a 7 x 7 patch of output positions have their origins in
+// the 8 x 8 block of pixels that starts one above and one left of it: 64 slots, one per lane
+// group.  Patches of neighbouring workgroups therefore overlap in their origin blocks by one row
+// / column (a footprint on a patch edge is walked by both, each keeping the corners inside its
+// own patch: 1.31 records per sampled point instead of 1.27), and no sum ever leaves the
+// workgroup.  At the end the four corner sums of every slot go through LDS once: output position
+// (y, x) of the patch adds corner (dy, dx) of slot (y + 1 - dy, x + 1 - dx).
+// Per round: one LDS atomic pair and one 16-byte entry per record (the position kernel: up to
+// four of each), a walk of about a third of the rows.  Rows of up to 32 channels (32 accumulator
+// registers per lane).
+// ---------------------------------------------------------------------------------------------
+template <typename VT, int G, int RPT, int U>
+__global__ __launch_bounds__(256) void bwd_tile_origin_kernel(
+    const VT* __restrict__ grad_out, const int64_t* __restrict__ shapes,
+    const int64_t* __restrict__ lsi, const uint4* __restrict__ records,
+    const uint2* __restrict__ dir, VT* __restrict__ grad_value, int S, int M, int Lq, int L,
+    BinPlan plan, int g_head_major) {
+  constexpr int CPL = Chunk<VT>::kCPL;
+  constexpr int D = G * CPL;
+  constexpr int PL = 4;                     // lanes per origin slot
+  constexpr int NS = 256 / PL;              // origin slots: 8 x 8
+  constexpr int NCH = D / (PL * CPL);       // 16-byte chunks of a row per lane
+  constexpr int R = 256 * RPT;              // records per round
+  constexpr int ROWB = D * sizeof(VT);
+  constexpr int TW = 7;                     // output patch: TW x TW positions
+  static_assert(NCH >= 1 && NCH * PL * CPL == D && NCH * CPL <= 8, "rows of up to 32 channels");
+  static_assert(NS == 64, "the slot scan is one wave wide");
+  extern __shared__ uint4 lds[];
+  __shared__ LevelInfo lv[kMaxLevelsTuned];
+  __shared__ TileMap tm;
+  __shared__ uint32_t n_runs_s;
+  __shared__ uint32_t scan_tmp[4];
+  __shared__ int tile_level_s, tile_y0_s, tile_x0_s;
+
+  // entries of a round (R x 16 bytes); reused for the corner exchange at the end (NS rows of D floats)
+  constexpr int kEntrySlots = R > NS * D / 4 ? R : NS * D / 4;
+  uint4* entries = lds;
+  uint32_t* cnt2 = reinterpret_cast<uint32_t*>(entries + kEntrySlots);  // 2 x NS: counts, then cursors
+  uint32_t* start = cnt2 + 2 * NS;                                      // NS + 1
+  uint32_t* run_first = start + NS + 1;                                 // n_qblocks + 1
+  uint32_t* run_base = run_first + plan.n_qblocks + 1;                  // n_qblocks
+
+  const int b = blockIdx.y;
+  const int m = blockIdx.x % M;
+  const int tile = plan.n_tiles - 1 - blockIdx.x / M;  // coarse (record-heavy) levels first
+  const int64_t slab = static_cast<int64_t>(b) * M + m;
+  MSDA_STAMP_DECL;
+  if (threadIdx.x < L) lv[threadIdx.x] = load_level(shapes, lsi, threadIdx.x, S);
+  if (threadIdx.x == 0) n_runs_s = 0;
+  if (threadIdx.x < 2 * NS) cnt2[threadIdx.x] = 0;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    build_tile_map(lv, L, plan, tm);
+    locate_tile(tm, L, plan, tile, tile_level_s, tile_y0_s, tile_x0_s);
+  }
+  for (int qbk = threadIdx.x; qbk < plan.n_qblocks; qbk += 256) {
+    const uint2 e = dir[(slab * plan.n_qblocks + qbk) * plan.n_tiles + tile];
+    if (e.y != 0 && e.x <= plan.region && e.y <= plan.region - e.x) {
+      const uint32_t at = atomicAdd(&n_runs_s, 1u);
+      run_first[at] = e.y;
+      run_base[at] = static_cast<uint32_t>(qbk) * plan.region + e.x;
+    }
+  }
+  __syncthreads();
+  const int n_runs = static_cast<int>(n_runs_s);
+  const uint32_t total = block_exclusive_scan(run_first, n_runs, scan_tmp);
+  if (threadIdx.x == 0) run_first[n_runs] = total;
+  __syncthreads();
+  MSDA_STAMP(0);  // level table, directory column, run scan
+  const int tl = tile_level_s;
+  if (tl < 0) return;  // (uniform: a tile id past the last tile)
+  const LevelInfo TL = lv[tl];
+  const int ty0 = tile_y0_s, tx0 = tile_x0_s;
+
+  const uint4* slab_records = records + slab * plan.n_qblocks * static_cast<int64_t>(plan.region);
+  const char* go_slab = reinterpret_cast<const char*>(grad_out) +
+                        (g_head_major ? slab * Lq : static_cast<int64_t>(b) * Lq * M + m) * ROWB;
+  const int pg = threadIdx.x / PL, pl = threadIdx.x % PL;
+  const uint32_t q_stride = static_cast<uint32_t>(g_head_major ? 1 : M) * ROWB;
+
+  float acc[4][NCH][CPL];  // [corner (y0,x0) (y0,x0+1) (y0+1,x0) (y0+1,x0+1)]
+#pragma unroll
+  for (int c4 = 0; c4 < 4; ++c4)
+#pragma unroll
+    for (int j = 0; j < NCH; ++j)
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) acc[c4][j][c] = 0.f;
+
+  int parity = 0;
+  for (uint32_t base = 0; base < total; base += R, parity ^= 1) {
+    uint32_t* cnt = cnt2 + parity * NS;
+    // ---- A: this thread's records of the round: origin slot, count ----
+    uint4 ent[RPT];       // {query, weight, lx, ly}
+    uint32_t slot[RPT];   // NS = not in this patch
+    uint4 recs[RPT];
+#pragma unroll
+    for (int j = 0; j < RPT; ++j) {
+      const uint32_t i = min(base + j * 256 + threadIdx.x, total - 1);
+      int lo = 0, hi = n_runs;  // run_first[lo] <= i < run_first[hi]
+      while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (run_first[mid] <= i) lo = mid; else hi = mid;
+      }
+      recs[j] = slab_records[run_base[lo] + (i - run_first[lo])];
+    }
+#pragma unroll
+    for (int j = 0; j < RPT; ++j) {
+      const uint32_t i = base + j * 256 + threadIdx.x;
+      slot[j] = NS;
+      const uint4 rec = recs[j];
+      const uint32_t q = rec.x & 0x0fffffffu;
+      // (a query index outside the tensor or another level's record can only come from a
+      // corrupted workspace: dropped before any address is formed from it)
+      if (i < total && q < static_cast<uint32_t>(Lq) && static_cast<int>(rec.x >> 28) == tl) {
+        // origin + 1 (0 .. H, 0 .. W): row / column 0 holds the footprints that hang over the edge
+        int oy, ox;
+        float ly, lx;
+        const bool any = footprint_origin(__uint_as_float(rec.z), __uint_as_float(rec.w), TL.H,
+                                          TL.W, oy, ox, ly, lx);
+        const int sy = oy - ty0, sx = ox - tx0;
+        if (any && sy >= 0 && sy <= TW && sx >= 0 && sx <= TW) {
+          slot[j] = static_cast<uint32_t>(sy * (TW + 1) + sx);
+          ent[j] = make_uint4(q, rec.y, __float_as_uint(lx), __float_as_uint(ly));
+          atomicAdd(&cnt[slot[j]], 1u);
+        }
+      }
+    }
+    MSDA_STAMP(1);
+    __syncthreads();
+    MSDA_STAMP(2);
+    // ---- B: exclusive scan of the 64 slot counts by wave 0; cnt becomes the cursor ----
+    if (threadIdx.x < NS) {
+      const uint32_t c = cnt[threadIdx.x];
+      const uint32_t incl = wave_inclusive_scan(c);
+      start[threadIdx.x] = incl - c;
+      cnt[threadIdx.x] = incl - c;
+      if (threadIdx.x == NS - 1) start[NS] = incl;
+      cnt2[(parity ^ 1) * NS + threadIdx.x] = 0;  // the next round's counts
+    }
+    __syncthreads();
+    MSDA_STAMP(3);
+    // ---- C: fill ----
+#pragma unroll
+    for (int j = 0; j < RPT; ++j)
+      if (slot[j] < NS) entries[atomicAdd(&cnt[slot[j]], 1u)] = ent[j];
+    MSDA_STAMP(4);
+    __syncthreads();
+    MSDA_STAMP(5);
+    // ---- D: walk the list of this lane group's origin slot ----
+    {
+      const uint32_t e0 = start[pg], e1 = start[pg + 1];
+      for (uint32_t e = e0; e < e1; e += U) {
+        float w[U][4], rv[U][NCH][CPL];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const uint4 en = entries[min(e + u, e1 - 1)];
+          const float a = e + u < e1 ? __uint_as_float(en.y) : 0.f;  // a repeated row adds nothing
+          const float lx = __uint_as_float(en.z), ly = __uint_as_float(en.w);
+          const float hx = 1.f - lx, hy = 1.f - ly;
+          w[u][0] = a * (hy * hx);
+          w[u][1] = a * (hy * lx);
+          w[u][2] = a * (ly * hx);
+          w[u][3] = a * (ly * lx);
+          const char* row = go_slab + (__umul24(en.x, q_stride) + pl * 16u);
+#pragma unroll
+          for (int j = 0; j < NCH; ++j) Chunk<VT>::load(row + j * PL * 16, rv[u][j]);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+          for (int c4 = 0; c4 < 4; ++c4)
+#pragma unroll
+            for (int j = 0; j < NCH; ++j)
+#pragma unroll
+              for (int c = 0; c < CPL; ++c) acc[c4][j][c] = fmaf(w[u][c4], rv[u][j][c], acc[c4][j][c]);
+      }
+    }
+    MSDA_STAMP(6);
+  }
+  MSDA_STAMP_FLUSH(1);
+
+  // ---- the four corner sums of every slot meet at their output positions ----
+  // lane group pg also owns output position (pg / 8, pg % 8) of the patch (when both are < 7)
+  float4* comb = reinterpret_cast<float4*>(entries);  // [slot][D / 4] floats
+  constexpr int F4 = D / 4;            // float4 per row
+  constexpr int F4L = NCH * CPL / 4;   // float4 per lane and row: the lane's channels, in order
+  const int py = pg >> 3, px = pg & 7;
+  float out[NCH][CPL];
+#pragma unroll
+  for (int j = 0; j < NCH; ++j)
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) out[j][c] = 0.f;
+#pragma unroll
+  for (int c4 = 0; c4 < 4; ++c4) {
+    __syncthreads();  // the last walk (c4 = 0) / the reads of the corner before are done
+#pragma unroll
+    for (int k = 0; k < F4L; ++k) {
+      const int j = (k * 4) / CPL, c = (k * 4) % CPL;
+      comb[pg * F4 + pl * F4L + k] =
+          make_float4(acc[c4][j][c], acc[c4][j][c + 1], acc[c4][j][c + 2], acc[c4][j][c + 3]);
+    }
+    __syncthreads();
+    const int sy = py + 1 - (c4 >> 1), sx = px + 1 - (c4 & 1);  // 0 .. 8; 8 only for unused groups
+    if (py < TW && px < TW) {
+#pragma unroll
+      for (int k = 0; k < F4L; ++k) {
+        const float4 v = comb[(sy * (TW + 1) + sx) * F4 + pl * F4L + k];
+        const int j = (k * 4) / CPL, c = (k * 4) % CPL;
+        out[j][c] += v.x;
+        out[j][c + 1] += v.y;
+        out[j][c + 2] += v.z;
+        out[j][c + 3] += v.w;
+      }
+    }
+  }
+  if (py >= TW || px >= TW) return;
+  const int yy = ty0 + py, xx = tx0 + px;
+  if (yy >= TL.H || xx >= TL.W) return;
+  const int64_t pos = TL.start + static_cast<int64_t>(yy) * TL.W + xx;
+  if (pos >= S) return;
+  // the lane's channels are chunks pl, pl + 4, ... of the row, as everywhere in these kernels
+  char* dst = reinterpret_cast<char*>(grad_value) +
+              (((static_cast<int64_t>(b) * S + pos) * M + m) * D) * sizeof(VT) + pl * 16;
+#pragma unroll
+  for (int j = 0; j < NCH; ++j) Chunk<VT>::store(dst + j * PL * 16, out[j]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1646,8 +1887,10 @@ __global__ __launch_bounds__(256) void bwd_tile_gather_det_kernel(
   if (plan.tile2d) {
     const int l = tile_level_s;
     if (l < 0) return;
-    const int yy = tile_y0_s + (pg >> plan.tw_shift);
-    const int xx = tile_x0_s + (pg & ((1 << plan.tw_shift) - 1));
+    if (pg >= plan.tw * plan.tw) return;
+    const int row = tile_div(pg, plan.tw);
+    const int yy = tile_y0_s + row;
+    const int xx = tile_x0_s + (pg - row * plan.tw);
     if (yy >= lv[l].H || xx >= lv[l].W) return;
     pos = lv[l].start + static_cast<int64_t>(yy) * lv[l].W + xx;
   } else {
@@ -1754,47 +1997,74 @@ inline int choose_qb(int G, int LP, int64_t n_tiles) {
   const auto resident = [&](int qb) {
     const int64_t lds = static_cast<int64_t>(GPB) * group_stride_slots(LP, stage_slots(kStageBwdBinned)) * 16 +
                         (2 * n_tiles + 3) / 4 * 16 + static_cast<int64_t>(qb / GPB - 1) * kpc * 3 * 1024;
-    return (160 * 1024) / (lds + 4096);  // (+ static arrays and allocation granularity)
+    return (160 * 1024) / (lds + 2560);  // (+ static arrays: 1.9 KB, and allocation granularity)
   };
   return resident(192) < 3 && resident(128) > resident(192) ? 128 : 192;
 }
 
+// Tile kernel by footprint origin (bwd_tile_origin_kernel, 7 x 7 patches) instead of by
+// destination position (8 x 8): -DMSDA_TILE_ORIGIN=0 builds the library without it, for A/B runs.
+#ifndef MSDA_TILE_ORIGIN
+#define MSDA_TILE_ORIGIN 1
+#endif
+// records per thread and round / entries per walk step of the origin kernel
+#ifndef MSDA_TO_RPT
+#define MSDA_TO_RPT 3
+#endif
+#ifndef MSDA_TO_U
+#define MSDA_TO_U 2
+#endif
+
+// `det`: the plan of the reproducible backward (MSDA_FLAG_DETERMINISTIC), whose tile kernel works
+// by destination position; the geometry (and with it the workspace size) depends on it.
 inline bool make_bin_plan(int N, int S, int M, int D, int Lq, int L, int P, int G,
                           const int64_t* levels_host, BinPlan* plan, size_t* dir_bytes,
-                          size_t* rec_bytes) {
+                          size_t* rec_bytes, bool det = false) {
   if (D > 64) return false;                  // accumulators of a position: D / 4 registers per lane
-  const int ts_shift = kTileShift, tw_shift = kTileWidthShift;
+  const int ts_shift = kTileShift;
   const int TS = 1 << ts_shift;
   const int64_t slabs = static_cast<int64_t>(N) * M;
   int64_t n_tiles = (static_cast<int64_t>(S) + TS - 1) / TS;
-  int64_t nt2d = -1;  // tile count of the 2-D geometry when the level table allows it
+  // tile counts of the 2-D geometries (7 x 7 and 8 x 8 patches) when the level table allows them
+  int64_t nt2d[2] = {-1, -1};
   if (levels_host != nullptr) {
-    const int tw = 1 << tw_shift, th = TS >> tw_shift;
-    int64_t total = 0, nt = 0;
-    bool ok = true;
+    int64_t total = 0, nt[2] = {0, 0};
+    bool ok = true, small = true;
     for (int l = 0; l < L; ++l) {
       const int64_t h = levels_host[2 * l], w = levels_host[2 * l + 1];
       if (h < 1 || w < 1 || h > S || w > S) { ok = false; break; }
       total += h * w;
-      nt += ((h + th - 1) / th) * ((w + tw - 1) / tw);
+      nt[0] += ((h + 6) / 7) * ((w + 6) / 7);
+      nt[1] += ((h + 7) / 8) * ((w + 7) / 8);
+      small = small && h <= kMaxExtentTile7 && w <= kMaxExtentTile7;
       if (total > S) { ok = false; break; }
     }
-    if (ok && total == S) nt2d = nt;
+    if (ok && total == S) {
+      nt2d[1] = nt[1];
+      // the origin kernel keeps four corner sums of a row in registers: rows of up to 32 channels
+      if (MSDA_TILE_ORIGIN && !det && small && D <= 32) nt2d[0] = nt[0];
+    }
   }
   // virtual queries per workgroup (split rows: always 128, one kernel variant fewer) and the
   // real queries they stand for
   const int split = G == 0 ? 1 : row_split(L * P);
-  const int qb = split > 1 ? 128 : choose_qb(G, L * P, nt2d >= 0 ? nt2d : n_tiles);
+  const int64_t nt_guess = nt2d[0] >= 0 ? nt2d[0] : nt2d[1] >= 0 ? nt2d[1] : n_tiles;
+  const int qb = split > 1 ? 128 : choose_qb(G, L * P, nt_guess);
   const int qpb = qb / split;
   const int64_t n_qblocks = (static_cast<int64_t>(Lq) + qpb - 1) / qpb;
   const auto fits = [&](int64_t nt) {
     return nt <= 4096 && slabs * n_qblocks * nt * 8 <= (static_cast<int64_t>(1) << 30) &&
            nt * M <= INT32_MAX;
   };
-  int tile2d = 0;
-  if (nt2d >= 0 && fits(nt2d)) {
-    n_tiles = nt2d;
+  int tile2d = 0, tw = 0;
+  if (nt2d[0] >= 0 && fits(nt2d[0])) {
+    n_tiles = nt2d[0];
     tile2d = 1;
+    tw = 7;
+  } else if (nt2d[1] >= 0 && fits(nt2d[1])) {
+    n_tiles = nt2d[1];
+    tile2d = 1;
+    tw = 8;
   }
   if (!fits(n_tiles) || n_qblocks > 2048 || Lq >= (1 << 28)) return false;
   const int64_t dir_b = slabs * n_qblocks * n_tiles * 8;
@@ -1808,7 +2078,7 @@ inline bool make_bin_plan(int N, int S, int M, int D, int Lq, int L, int P, int 
   plan->n_qblocks = static_cast<int>(n_qblocks);
   plan->region = static_cast<uint32_t>(region);
   plan->tile2d = tile2d;
-  plan->tw_shift = tw_shift;
+  plan->tw = tw;
   plan->in_order = 1;
   plan->phase = kPhaseBin | kPhaseGrad;
   plan->q_per_block = qpb;
@@ -1939,11 +2209,22 @@ inline int64_t tuned_backward_workspace_bytes(int N, int S, int M, int D, int Lq
   if (!tuned_shape_ok(N, S, M, D, Lq, L, P, dtype_val, dtype_loc, &G)) return -1;
   BinPlan plan;
   size_t dir_b, rec_b;
-  if (allow_binned && make_bin_plan(N, S, M, D, Lq, L, P, G, levels_host, &plan, &dir_b, &rec_b))
+  if (allow_binned && make_bin_plan(N, S, M, D, Lq, L, P, G, levels_host, &plan, &dir_b, &rec_b, det))
     return static_cast<int64_t>(dir_b + rec_b + g_copy_bytes(N, M, D, Lq, dtype_val));
   if (det) return -1;  // reproducible form: binned path only, else the caller's generic gather
   if (dtype_val == 0) return 0;
   return static_cast<int64_t>(N) * S * M * D * 4;  // fp32 accumulation image of grad_value
+}
+
+// (the plan picks 7 x 7 patches only for rows the origin kernel is built for)
+template <typename VT, int GG, int RR, int UU, typename... Args>
+inline void launch_tile_origin(Launches& run, dim3 grid, size_t lds_bytes, hipStream_t stream,
+                               Args... args) {
+  if constexpr (GG * Chunk<VT>::kCPL <= 32) {
+    run((bwd_tile_origin_kernel<VT, GG, RR, UU>), grid, dim3(256), lds_bytes, stream, args...);
+  } else {
+    run.rc = static_cast<int>(hipErrorInvalidValue);
+  }
 }
 
 template <typename VT, typename LT>
@@ -1964,7 +2245,7 @@ int tuned_backward_typed(const void* grad_out, const void* value, const int64_t*
   BinPlan plan{};
   size_t dir_b = 0, rec_b = 0;
   const bool binned =
-      allow_binned && make_bin_plan(N, S, M, D, Lq, L, P, G, levels_host, &plan, &dir_b, &rec_b);
+      allow_binned && make_bin_plan(N, S, M, D, Lq, L, P, G, levels_host, &plan, &dir_b, &rec_b, det);
   const int slots = stage_slots(binned ? kStageBwdBinned : kStageBwdAtomic);
   int LPB = stage_points_per_pass(GQ, LP, slots);
   // Register-resident points (see bwd_query_kernel): 4 lanes per query, three chunks of 64
@@ -2003,6 +2284,12 @@ int tuned_backward_typed(const void* grad_out, const void* value, const int64_t*
     constexpr int RPT = 2;
     const size_t tlds = 4 * 256 * static_cast<size_t>(RPT) * 8 + (3 * TSz + 1) * 4 +
                         (2 * static_cast<size_t>(plan.n_qblocks) + 1) * 4;
+    // by origin: 16-byte entries of a round or the corner exchange (64 rows of D floats)
+    constexpr size_t kRowF32 = static_cast<size_t>(Chunk<VT>::kCPL) * 4;  // bytes of a chunk as floats
+    const size_t oex = static_cast<size_t>(64) * G * kRowF32;
+    const size_t oent = static_cast<size_t>(256) * MSDA_TO_RPT * 16;
+    const size_t olds = (oent > oex ? oent : oex) + (3 * TSz + 1) * 4 +
+                        (2 * static_cast<size_t>(plan.n_qblocks) + 1) * 4;
     // reproducible form: two entry arrays of 4 * 512, one count array
     const size_t dlds = 2 * 4 * 512 * 8 + (2 * TSz + 1) * 4 +
                         (2 * static_cast<size_t>(plan.n_qblocks) + 1) * 4;
@@ -2011,6 +2298,12 @@ int tuned_backward_typed(const void* grad_out, const void* value, const int64_t*
                      g_copy ? static_cast<const VT*>(g_copy) : static_cast<const VT*>(grad_out), \
                      shapes, lsi, records, dir, static_cast<VT*>(grad_value), S, M, Lq, L, plan, \
                      g_copy ? 1 : 0)
+#define MSDA_TILE_ORIGIN_K(GG, RR, UU)                                                           \
+  launch_tile_origin<VT, GG, RR, UU>(                                                            \
+      run, tgrid, olds, stream,                                                                  \
+      g_copy ? static_cast<const VT*>(g_copy) : static_cast<const VT*>(grad_out), shapes, lsi,   \
+      static_cast<const uint4*>(records), static_cast<const uint2*>(dir),                        \
+      static_cast<VT*>(grad_value), S, M, Lq, L, plan, g_copy ? 1 : 0)
 #define MSDA_TILE_DET(GG)                                                                        \
   run((bwd_tile_gather_det_kernel<VT, GG>), tgrid, dim3(256), dlds, stream,                      \
       g_copy ? static_cast<const VT*>(g_copy) : static_cast<const VT*>(grad_out), shapes, lsi,   \
@@ -2041,7 +2334,11 @@ int tuned_backward_typed(const void* grad_out, const void* value, const int64_t*
   }                                                                                              \
   if (phase & kPhaseGrad) {                                                                      \
     if (det) return kNotTuned;                                                                   \
-    MSDA_TILE(GG, RPT, UU);                                                                      \
+    if (plan.tile2d && plan.tw == 7) {                                                           \
+      MSDA_TILE_ORIGIN_K(GG, MSDA_TO_RPT, MSDA_TO_U);                                            \
+    } else {                                                                                     \
+      MSDA_TILE(GG, RPT, UU);                                                                    \
+    }                                                                                            \
   }
 #else
 #define MSDA_TB(GG, UU)                                                                          \
@@ -2059,6 +2356,8 @@ int tuned_backward_typed(const void* grad_out, const void* value, const int64_t*
   if (phase & kPhaseGrad) {                                                                      \
     if (det) {                                                                                   \
       MSDA_TILE_DET(GG);                                                                         \
+    } else if (plan.tile2d && plan.tw == 7) {                                                    \
+      MSDA_TILE_ORIGIN_K(GG, MSDA_TO_RPT, MSDA_TO_U);                                            \
     } else {                                                                                     \
       MSDA_TILE(GG, RPT, UU);                                                                    \
     }                                                                                            \
@@ -2076,6 +2375,7 @@ int tuned_backward_typed(const void* grad_out, const void* value, const int64_t*
 #undef MSDA_TQB
 #undef MSDA_TILE
 #undef MSDA_TILE_DET
+#undef MSDA_TILE_ORIGIN_K
     return run.rc;
   }
 
@@ -2091,7 +2391,7 @@ int tuned_backward_typed(const void* grad_out, const void* value, const int64_t*
   plan.n_qblocks = (Lq + plan.qb - 1) / plan.qb;
   plan.n_tiles = 0;
   plan.tile2d = 0;
-  plan.tw_shift = 0;
+  plan.tw = 0;
   plan.in_order = 1;
   const dim3 grid(static_cast<unsigned>(plan.n_qblocks) * M, N);
   const size_t lds = static_cast<size_t>(GPB) * group_stride_slots(LPB, slots) * 16;
@@ -2145,13 +2445,14 @@ inline int tuned_backward(const void* grad_out, const void* value, const int64_t
 #if MSDA_EXP_MIN
   if (dtype_val != 0 || G != 8) return kNotTuned;
   return tuned_backward_typed<float, float>(MSDA_ARGS);
-#endif
+#else
   if (dtype_val == 0) return tuned_backward_typed<float, float>(MSDA_ARGS);
   if (dtype_val == 2)
     return dtype_loc == 0 ? tuned_backward_typed<bf16_t, float>(MSDA_ARGS)
                           : tuned_backward_typed<bf16_t, bf16_t>(MSDA_ARGS);
   return dtype_loc == 0 ? tuned_backward_typed<f16_t, float>(MSDA_ARGS)
                         : tuned_backward_typed<f16_t, f16_t>(MSDA_ARGS);
+#endif
 #undef MSDA_ARGS
 }
 
