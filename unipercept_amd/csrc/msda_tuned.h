@@ -419,6 +419,9 @@ struct EmitCtx {
 // What a staged point holds: forward {weights, offsets}; backward with atomic scatter {weights,
 // offsets, fractions}; backward with binned scatter {offsets, fractions}.
 enum StageKind { kStageFwd = 0, kStageBwdAtomic = 1, kStageBwdBinned = 2 };
+// staged offset of a corner outside its level in the binned backward: beyond any value slab
+// (slabs are at most 4 GB - 512 bytes there), and lane offsets (< 256) do not wrap it around
+constexpr uint32_t kOffsetOutside = 0xFFFFFF00u;
 __host__ __device__ constexpr int stage_slots(int kind) { return kind == kStageBwdAtomic ? 3 : 2; }
 
 // Raw sampling points: locations and weights still as the layer's projection left them, i.e.
@@ -490,6 +493,15 @@ __device__ __forceinline__ void stage_point(const LevelInfo& L_, int l, float x,
   orec.y = (__umul24(static_cast<uint32_t>(L_.start + f.pix[1]), rowb) + headb) | (f.valid[1] ? 1u : 0u);
   orec.z = (__umul24(static_cast<uint32_t>(L_.start + f.pix[2]), rowb) + headb) | (f.valid[2] ? 1u : 0u);
   orec.w = (__umul24(static_cast<uint32_t>(L_.start + f.pix[3]), rowb) + headb) | (f.valid[3] ? 1u : 0u);
+  if constexpr (KIND == kStageBwdBinned && MSDA_K3_DEPTH == 2) {
+    // the binned query kernel gathers through a buffer descriptor of the value slab: a corner
+    // outside the level gets an offset past the slab, which reads as zeros — no validity test
+    // and no masking in the gather loop (offsets of corners inside stay plain multiples of 16)
+    orec.x = f.valid[0] ? orec.x & ~15u : kOffsetOutside;
+    orec.y = f.valid[1] ? orec.y & ~15u : kOffsetOutside;
+    orec.z = f.valid[2] ? orec.z & ~15u : kOffsetOutside;
+    orec.w = f.valid[3] ? orec.w & ~15u : kOffsetOutside;
+  }
   if constexpr (KIND != kStageBwdBinned) dst[0] = wrec;
   dst[KIND == kStageBwdBinned ? 0 : 1] = orec;
   if constexpr (KIND != kStageFwd) {
@@ -1048,14 +1060,13 @@ __global__ __launch_bounds__(256, MSDA_K3_MINWAVES) void bwd_query_kernel(
 #pragma unroll
           for (int j = 0; j < NC; ++j)
             pr.raw[c4][j] = __builtin_amdgcn_raw_buffer_load_b128(
-                vres, static_cast<int>((oraw[c4] & ~15u) + lane_b + j * GQ * 16), 0, 0);
+                vres, static_cast<int>(oraw[c4] + lane_b + j * GQ * 16), 0, 0);
       };
       float keep_sv = 0.f, keep_sx = 0.f, keep_sy = 0.f, keep_a = 0.f;
       // raw points: weight and weight gradient of this lane's point of every pass, for the
       // softmax backward d logit_i = w_i * (g_i - sum_k w_k g_k) once all points are through
       float ka[4] = {0.f, 0.f, 0.f, 0.f}, kg[4] = {0.f, 0.f, 0.f, 0.f};
       const auto consume = [&](const PointRegs& pr, int k) {
-        const uint32_t oraw[4] = {pr.orr.x, pr.orr.y, pr.orr.z, pr.orr.w};
         const float lx = __uint_as_float(pr.fr.x), ly = __uint_as_float(pr.fr.y);
         const float aW = __uint_as_float(pr.fr.z), aH = __uint_as_float(pr.fr.w);
         const float hx = 1.f - lx, hy = 1.f - ly;
@@ -1066,7 +1077,7 @@ __global__ __launch_bounds__(256, MSDA_K3_MINWAVES) void bwd_query_kernel(
 #pragma unroll
           for (int j = 0; j < NC; ++j)
             d = Chunk<VT>::dot(go_raw[j], __builtin_bit_cast(uint4, pr.raw[c4][j]), d);
-          dot[c4] = (oraw[c4] & 1u) ? d : 0.f;  // a corner outside the level contributes nothing
+          dot[c4] = d;  // (a corner outside the level read zeros)
         }
         // w = {hy*hx, hy*lx, ly*hx, ly*lx}; dw/dx = {-hy, hy, -ly, ly}; dw/dy = {-hx, -lx, hx, lx}
         float sv = hy * fmaf(hx, dot[0], lx * dot[1]) + ly * fmaf(hx, dot[2], lx * dot[3]);
@@ -1487,18 +1498,23 @@ __global__ __launch_bounds__(256) void bwd_tile_gather_kernel(
 // four of each), a walk of about a third of the rows.  Rows of up to 32 channels (32 accumulator
 // registers per lane).
 // ---------------------------------------------------------------------------------------------
-template <typename VT, int G, int RPT, int U>
-__global__ __launch_bounds__(256) void bwd_tile_origin_kernel(
+#ifndef MSDA_TO_MINWAVES
+#define MSDA_TO_MINWAVES 1
+#endif
+
+template <typename VT, int G, int RPT, int U, int PL = 4>
+__global__ __launch_bounds__(64 * PL, MSDA_TO_MINWAVES) void bwd_tile_origin_kernel(
     const VT* __restrict__ grad_out, const int64_t* __restrict__ shapes,
     const int64_t* __restrict__ lsi, const uint4* __restrict__ records,
     const uint2* __restrict__ dir, VT* __restrict__ grad_value, int S, int M, int Lq, int L,
     BinPlan plan, int g_head_major) {
   constexpr int CPL = Chunk<VT>::kCPL;
   constexpr int D = G * CPL;
-  constexpr int PL = 4;                     // lanes per origin slot
-  constexpr int NS = 256 / PL;              // origin slots: 8 x 8
+  // PL lanes per origin slot (4, or 8: half the accumulators per lane, twice the waves)
+  constexpr int NS = 64;                    // origin slots: 8 x 8
+  constexpr int NT = NS * PL;               // threads
   constexpr int NCH = D / (PL * CPL);       // 16-byte chunks of a row per lane
-  constexpr int R = 256 * RPT;              // records per round
+  constexpr int R = NT * RPT;               // records per round
   constexpr int ROWB = D * sizeof(VT);
   constexpr int TW = 7;                     // output patch: TW x TW positions
   static_assert(NCH >= 1 && NCH * PL * CPL == D && NCH * CPL <= 8, "rows of up to 32 channels");
@@ -1507,7 +1523,7 @@ __global__ __launch_bounds__(256) void bwd_tile_origin_kernel(
   __shared__ LevelInfo lv[kMaxLevelsTuned];
   __shared__ TileMap tm;
   __shared__ uint32_t n_runs_s;
-  __shared__ uint32_t scan_tmp[4];
+  __shared__ uint32_t scan_tmp[8];
   __shared__ int tile_level_s, tile_y0_s, tile_x0_s;
 
   // entries of a round (R x 16 bytes); reused for the corner exchange at the end (NS rows of D floats)
@@ -1531,7 +1547,7 @@ __global__ __launch_bounds__(256) void bwd_tile_origin_kernel(
     build_tile_map(lv, L, plan, tm);
     locate_tile(tm, L, plan, tile, tile_level_s, tile_y0_s, tile_x0_s);
   }
-  for (int qbk = threadIdx.x; qbk < plan.n_qblocks; qbk += 256) {
+  for (int qbk = threadIdx.x; qbk < plan.n_qblocks; qbk += NT) {
     const uint2 e = dir[(slab * plan.n_qblocks + qbk) * plan.n_tiles + tile];
     if (e.y != 0 && e.x <= plan.region && e.y <= plan.region - e.x) {
       const uint32_t at = atomicAdd(&n_runs_s, 1u);
@@ -1555,6 +1571,12 @@ __global__ __launch_bounds__(256) void bwd_tile_origin_kernel(
                         (g_head_major ? slab * Lq : static_cast<int64_t>(b) * Lq * M + m) * ROWB;
   const int pg = threadIdx.x / PL, pl = threadIdx.x % PL;
   const uint32_t q_stride = static_cast<uint32_t>(g_head_major ? 1 : M) * ROWB;
+  // the rows of this (batch, head) come in through a buffer descriptor: one 32-bit offset per
+  // load instead of a 64-bit address, and an offset past the rows reads zeros
+  const uint32_t go_bytes = static_cast<uint32_t>(Lq - 1) * q_stride + ROWB;
+  const __amdgpu_buffer_rsrc_t gres = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<char*>(go_slab), 0, static_cast<int>(go_bytes), 0x00020000);
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
   float acc[4][NCH][CPL];  // [corner (y0,x0) (y0,x0+1) (y0+1,x0) (y0+1,x0+1)]
 #pragma unroll
@@ -1573,7 +1595,7 @@ __global__ __launch_bounds__(256) void bwd_tile_origin_kernel(
     uint4 recs[RPT];
 #pragma unroll
     for (int j = 0; j < RPT; ++j) {
-      const uint32_t i = min(base + j * 256 + threadIdx.x, total - 1);
+      const uint32_t i = min(base + j * NT + threadIdx.x, total - 1);
       int lo = 0, hi = n_runs;  // run_first[lo] <= i < run_first[hi]
       while (hi - lo > 1) {
         const int mid = (lo + hi) >> 1;
@@ -1583,7 +1605,7 @@ __global__ __launch_bounds__(256) void bwd_tile_origin_kernel(
     }
 #pragma unroll
     for (int j = 0; j < RPT; ++j) {
-      const uint32_t i = base + j * 256 + threadIdx.x;
+      const uint32_t i = base + j * NT + threadIdx.x;
       slot[j] = NS;
       const uint4 rec = recs[j];
       const uint32_t q = rec.x & 0x0fffffffu;
@@ -1639,9 +1661,12 @@ __global__ __launch_bounds__(256) void bwd_tile_origin_kernel(
           w[u][1] = a * (hy * lx);
           w[u][2] = a * (ly * hx);
           w[u][3] = a * (ly * lx);
-          const char* row = go_slab + (__umul24(en.x, q_stride) + pl * 16u);
+          const uint32_t row = __umul24(en.x, q_stride) + pl * 16u;
 #pragma unroll
-          for (int j = 0; j < NCH; ++j) Chunk<VT>::load(row + j * PL * 16, rv[u][j]);
+          for (int j = 0; j < NCH; ++j)
+            Chunk<VT>::unpack(__builtin_bit_cast(uint4, static_cast<u32x4>(__builtin_amdgcn_raw_buffer_load_b128(
+                                  gres, static_cast<int>(row + j * PL * 16), 0, 0))),
+                              rv[u][j]);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u)
@@ -1932,7 +1957,8 @@ inline bool tuned_shape_ok(int N, int S, int M, int D, int Lq, int L, int P, int
   if (G != 4 && G != 8 && G != 16) return false;
   if (L > kMaxLevelsTuned) return false;
   const int esize = cpl == 4 ? 4 : 2;
-  if (static_cast<int64_t>(S) * M * D * esize > static_cast<int64_t>(UINT32_MAX)) return false;
+  // (512 bytes short of 4 GB: see kOffsetOutside)
+  if (static_cast<int64_t>(S) * M * D * esize > static_cast<int64_t>(UINT32_MAX) - 512) return false;
   // the kernels form pixel, row and query offsets with 24-bit multiplies and 32-bit sums
   if (S >= (1 << 24) || Lq >= (1 << 24) || static_cast<int64_t>(M) * D * esize >= (1 << 24) ||
       static_cast<int64_t>(M) * 3 * L * P >= (1 << 24) ||
@@ -2217,11 +2243,22 @@ inline int64_t tuned_backward_workspace_bytes(int N, int S, int M, int D, int Lq
 }
 
 // (the plan picks 7 x 7 patches only for rows the origin kernel is built for)
+// lanes per origin slot of the origin kernel: 8 where a row has 8 chunks (fp32, 32 channels)
+#ifndef MSDA_TO_PL8
+#define MSDA_TO_PL8 0
+#endif
+#ifndef MSDA_TO_LDS_PAD
+#define MSDA_TO_LDS_PAD 0  // diagnostic builds: unused LDS, to lower the number of resident workgroups
+#endif
+template <typename VT, int GG>
+constexpr int origin_lanes() { return MSDA_TO_PL8 && GG == 8 ? 8 : 4; }
+
 template <typename VT, int GG, int RR, int UU, typename... Args>
 inline void launch_tile_origin(Launches& run, dim3 grid, size_t lds_bytes, hipStream_t stream,
                                Args... args) {
   if constexpr (GG * Chunk<VT>::kCPL <= 32) {
-    run((bwd_tile_origin_kernel<VT, GG, RR, UU>), grid, dim3(256), lds_bytes, stream, args...);
+    constexpr int PL = origin_lanes<VT, GG>();
+    run((bwd_tile_origin_kernel<VT, GG, RR, UU, PL>), grid, dim3(64 * PL), lds_bytes, stream, args...);
   } else {
     run.rc = static_cast<int>(hipErrorInvalidValue);
   }
@@ -2287,9 +2324,9 @@ int tuned_backward_typed(const void* grad_out, const void* value, const int64_t*
     // by origin: 16-byte entries of a round or the corner exchange (64 rows of D floats)
     constexpr size_t kRowF32 = static_cast<size_t>(Chunk<VT>::kCPL) * 4;  // bytes of a chunk as floats
     const size_t oex = static_cast<size_t>(64) * G * kRowF32;
-    const size_t oent = static_cast<size_t>(256) * MSDA_TO_RPT * 16;
+    const size_t oent = static_cast<size_t>(64) * (MSDA_TO_PL8 && G == 8 ? 8 : 4) * MSDA_TO_RPT * 16;
     const size_t olds = (oent > oex ? oent : oex) + (3 * TSz + 1) * 4 +
-                        (2 * static_cast<size_t>(plan.n_qblocks) + 1) * 4;
+                        (2 * static_cast<size_t>(plan.n_qblocks) + 1) * 4 + MSDA_TO_LDS_PAD;
     // reproducible form: two entry arrays of 4 * 512, one count array
     const size_t dlds = 2 * 4 * 512 * 8 + (2 * TSz + 1) * 4 +
                         (2 * static_cast<size_t>(plan.n_qblocks) + 1) * 4;
