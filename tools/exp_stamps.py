@@ -24,12 +24,12 @@ import numpy as np
 G = 1 << 15
 buf = (ctypes.c_ulonglong * (G * 16))()
 names = [["levels+tilemap", "issue point loads", "zero counters", "count (waits loads)", "scan+dir row", "park + stage first chunk (after emit)", "barrier after stage", "go row load+copy", "gather+dots+stores", "barrier after gather", "emit: records into the LDS image", "emit: barrier", "emit: linear copy + barrier"],
-         ["setup: dir column + run scan", "A records+count own", "barrier A", "B scan", "C fill own", "barrier C", "D walk own", "barrier D"]]
+         ["setup: dir column + run scan", "A records+count own (fused: first rounds of all patches)", "barrier A", "B scan", "C fill own", "barrier C", "D walk own", "corner exchange + store"]]
 for which, kname in ((0, "bwd_query_kernel"), (1, "bwd_tile_gather_kernel")):
     lib.msda_debug_read_stamps.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
     got = lib.msda_debug_read_stamps(which, buf, G)
     a = np.frombuffer(buf, dtype=np.uint64).reshape(G, 16).astype(np.float64)
-    if which == 1 and os.environ.get("TILE"):
+    if which == 1 and os.environ.get("TILE") and not os.environ.get("NOLEVELS"):
         # per level: workgroup (batch, tile*M + head), coarse levels first
         t = int(os.environ["TILE"]); per = [(-(-h // t)) * (-(-ww // t)) for h, ww in w.levels]
         gx = sum(per) * m; life = a.sum(1)

@@ -1498,73 +1498,116 @@ __global__ __launch_bounds__(256) void bwd_tile_gather_kernel(
 // four of each), a walk of about a third of the rows.  Rows of up to 32 channels (32 accumulator
 // registers per lane).
 // ---------------------------------------------------------------------------------------------
-#ifndef MSDA_TO_MINWAVES
-#define MSDA_TO_MINWAVES 1
+// What the origin kernel knows about the pyramid, handed over as a kernel argument (the host has
+// the level shapes whenever this kernel is chosen): no table load and no tile map to build at
+// the start of every workgroup.  Patches of the fine levels, which receive few records each, are
+// taken several per workgroup (`per`), so that the latencies of a patch's set-up — its directory
+// column, its first records — are paid once per group instead of once per patch.
+constexpr int kOriginMaxLevels = 8;
+#ifndef MSDA_TO_T
+#define MSDA_TO_T 2
 #endif
+#ifndef MSDA_TO_RPT0
+#define MSDA_TO_RPT0 2
+#endif
+constexpr int kOriginMaxFuse = MSDA_TO_T;      // patches per workgroup, at most
+constexpr int kOriginFuseRecords = MSDA_TO_RPT0;  // records per thread and patch of a fused first round
+struct OriginLevels {
+  int H[kOriginMaxLevels], W[kOriginMaxLevels], start[kOriginMaxLevels];
+  int tstart[kOriginMaxLevels + 1];  // first patch id of every level
+  int tx[kOriginMaxLevels];          // patches per row
+  int gstart[kOriginMaxLevels + 1];  // first workgroup (group of patches) of every level
+  int per[kOriginMaxLevels];         // patches per workgroup on the level
+};
 
-template <typename VT, int G, int RPT, int U, int PL = 4>
-__global__ __launch_bounds__(64 * PL, MSDA_TO_MINWAVES) void bwd_tile_origin_kernel(
-    const VT* __restrict__ grad_out, const int64_t* __restrict__ shapes,
-    const int64_t* __restrict__ lsi, const uint4* __restrict__ records,
+template <typename VT, int G, int RPT, int U>
+__global__ __launch_bounds__(256) void bwd_tile_origin_kernel(
+    const VT* __restrict__ grad_out, const uint4* __restrict__ records,
     const uint2* __restrict__ dir, VT* __restrict__ grad_value, int S, int M, int Lq, int L,
-    BinPlan plan, int g_head_major) {
+    BinPlan plan, int g_head_major, OriginLevels lvls) {
   constexpr int CPL = Chunk<VT>::kCPL;
   constexpr int D = G * CPL;
-  // PL lanes per origin slot (4, or 8: half the accumulators per lane, twice the waves)
+  constexpr int PL = 4;                     // lanes per origin slot
   constexpr int NS = 64;                    // origin slots: 8 x 8
   constexpr int NT = NS * PL;               // threads
   constexpr int NCH = D / (PL * CPL);       // 16-byte chunks of a row per lane
-  constexpr int R = NT * RPT;               // records per round
+  constexpr int R = NT * RPT;               // records per round (one patch per workgroup)
+  constexpr int T = kOriginMaxFuse;
+  constexpr int RPT0 = kOriginFuseRecords;
+  constexpr int R0 = NT * RPT0;             // records per round and patch (several per workgroup)
   constexpr int ROWB = D * sizeof(VT);
   constexpr int TW = 7;                     // output patch: TW x TW positions
   static_assert(NCH >= 1 && NCH * PL * CPL == D && NCH * CPL <= 8, "rows of up to 32 channels");
-  static_assert(NS == 64, "the slot scan is one wave wide");
+  static_assert(NS * D / 4 <= R0, "the corner exchange fits an entry region");
+  static_assert(R <= T * R0, "a round of a single patch fits the entry regions");
+  static_assert(T * NS <= NT && T <= NT / 64, "a thread per fused slot counter, a wave per patch");
   extern __shared__ uint4 lds[];
-  __shared__ LevelInfo lv[kMaxLevelsTuned];
-  __shared__ TileMap tm;
-  __shared__ uint32_t n_runs_s;
-  __shared__ uint32_t scan_tmp[8];
-  __shared__ int tile_level_s, tile_y0_s, tile_x0_s;
+  __shared__ uint32_t n_runs_s[T];
 
-  // entries of a round (R x 16 bytes); reused for the corner exchange at the end (NS rows of D floats)
-  constexpr int kEntrySlots = R > NS * D / 4 ? R : NS * D / 4;
-  uint4* entries = lds;
-  uint32_t* cnt2 = reinterpret_cast<uint32_t*>(entries + kEntrySlots);  // 2 x NS: counts, then cursors
+  // LDS: T regions of R0 16-byte entries — region k holds the entries of patch k and then its
+  // corner exchange, a workgroup with a single patch uses them all as one round buffer; slot
+  // counters / list starts of the fused first rounds and of the later rounds; run tables of the
+  // T patches.
+  uint4* region = lds;
+  uint32_t* cntA = reinterpret_cast<uint32_t*>(region + T * R0);        // T x NS
+  uint32_t* startA = cntA + T * NS;                                     // T x (NS + 1)
+  uint32_t* cnt2 = startA + T * (NS + 1);                               // 2 x NS
   uint32_t* start = cnt2 + 2 * NS;                                      // NS + 1
-  uint32_t* run_first = start + NS + 1;                                 // n_qblocks + 1
-  uint32_t* run_base = run_first + plan.n_qblocks + 1;                  // n_qblocks
+  uint32_t* run_tab = start + NS + 1;                                   // per patch: n_qblocks + 1 starts, n_qblocks bases
+  const int tab_words = 2 * plan.n_qblocks + 1;
 
   const int b = blockIdx.y;
   const int m = blockIdx.x % M;
-  const int tile = plan.n_tiles - 1 - blockIdx.x / M;  // coarse (record-heavy) levels first
+  const int group = lvls.gstart[L] - 1 - static_cast<int>(blockIdx.x / M);  // coarse levels first
   const int64_t slab = static_cast<int64_t>(b) * M + m;
   MSDA_STAMP_DECL;
-  if (threadIdx.x < L) lv[threadIdx.x] = load_level(shapes, lsi, threadIdx.x, S);
-  if (threadIdx.x == 0) n_runs_s = 0;
+  if (group < 0) return;
+  int tl = 0;
+  for (int l = 1; l < L; ++l)
+    if (group >= lvls.gstart[l]) tl = l;
+  const int H = lvls.H[tl], W = lvls.W[tl], lstart = lvls.start[tl], txl = lvls.tx[tl];
+  const int t_first = lvls.tstart[tl] + (group - lvls.gstart[tl]) * lvls.per[tl];
+  const int nt = min(min(lvls.per[tl], T), lvls.tstart[tl + 1] - t_first);  // patches of this workgroup
+  if (nt < 1) return;
+
+  if (threadIdx.x < T) n_runs_s[threadIdx.x] = 0;
+  if (threadIdx.x < T * NS) cntA[threadIdx.x] = 0;
   if (threadIdx.x < 2 * NS) cnt2[threadIdx.x] = 0;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    build_tile_map(lv, L, plan, tm);
-    locate_tile(tm, L, plan, tile, tile_level_s, tile_y0_s, tile_x0_s);
-  }
-  for (int qbk = threadIdx.x; qbk < plan.n_qblocks; qbk += NT) {
-    const uint2 e = dir[(slab * plan.n_qblocks + qbk) * plan.n_tiles + tile];
-    if (e.y != 0 && e.x <= plan.region && e.y <= plan.region - e.x) {
-      const uint32_t at = atomicAdd(&n_runs_s, 1u);
-      run_first[at] = e.y;
-      run_base[at] = static_cast<uint32_t>(qbk) * plan.region + e.x;
+  // the directory columns of the patches: their non-empty runs (record count, first record)
+#pragma unroll
+  for (int k = 0; k < T; ++k) {
+    if (k < nt) {
+      uint32_t* rf = run_tab + k * tab_words;
+      uint32_t* rb = rf + plan.n_qblocks + 1;
+      for (int qbk = threadIdx.x; qbk < plan.n_qblocks; qbk += NT) {
+        const uint2 e = dir[(slab * plan.n_qblocks + qbk) * plan.n_tiles + t_first + k];
+        // (a run that does not fit its region can only come from a corrupted directory: skipped)
+        if (e.y != 0 && e.x <= plan.region && e.y <= plan.region - e.x) {
+          const uint32_t at = atomicAdd(&n_runs_s[k], 1u);
+          rf[at] = e.y;
+          rb[at] = static_cast<uint32_t>(qbk) * plan.region + e.x;
+        }
+      }
     }
   }
   __syncthreads();
-  const int n_runs = static_cast<int>(n_runs_s);
-  const uint32_t total = block_exclusive_scan(run_first, n_runs, scan_tmp);
-  if (threadIdx.x == 0) run_first[n_runs] = total;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (wave < nt) {  // wave k turns the run lengths of patch k into run starts
+    uint32_t* rf = run_tab + wave * tab_words;
+    const int n = static_cast<int>(n_runs_s[wave]);
+    uint32_t carry = 0;
+    for (int b0 = 0; b0 < n; b0 += 64) {
+      const int i = b0 + lane;
+      const uint32_t x = i < n ? rf[i] : 0u;
+      const uint32_t incl = wave_inclusive_scan(x);
+      if (i < n) rf[i] = carry + incl - x;
+      carry += static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(incl), 63));
+    }
+    if (lane == 0) rf[n] = carry;
+  }
   __syncthreads();
-  MSDA_STAMP(0);  // level table, directory column, run scan
-  const int tl = tile_level_s;
-  if (tl < 0) return;  // (uniform: a tile id past the last tile)
-  const LevelInfo TL = lv[tl];
-  const int ty0 = tile_y0_s, tx0 = tile_x0_s;
+  MSDA_STAMP(0);  // directory columns, run scans
 
   const uint4* slab_records = records + slab * plan.n_qblocks * static_cast<int64_t>(plan.region);
   const char* go_slab = reinterpret_cast<const char*>(grad_out) +
@@ -1579,153 +1622,250 @@ __global__ __launch_bounds__(64 * PL, MSDA_TO_MINWAVES) void bwd_tile_origin_ker
   typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
   float acc[4][NCH][CPL];  // [corner (y0,x0) (y0,x0+1) (y0+1,x0) (y0+1,x0+1)]
+  const auto clear_acc = [&]() {
 #pragma unroll
-  for (int c4 = 0; c4 < 4; ++c4)
+    for (int c4 = 0; c4 < 4; ++c4)
+#pragma unroll
+      for (int j = 0; j < NCH; ++j)
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) acc[c4][j][c] = 0.f;
+  };
+  // record i of a patch's list (runs `rf` / `rb`, n of them)
+  const auto load_record = [&](const uint32_t* rf, const uint32_t* rb, int n, uint32_t i) {
+    int lo = 0, hi = n;  // rf[lo] <= i < rf[hi]
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (rf[mid] <= i) lo = mid; else hi = mid;
+    }
+    return slab_records[rb[lo] + (i - rf[lo])];
+  };
+  // origin slot of a record in the patch whose first output position is (ty0, tx0); NS when the
+  // record does not belong here (a query index outside the tensor or another level's record can
+  // only come from a corrupted workspace: dropped before any address is formed from it)
+  const auto slot_of = [&](const uint4& rec, int ty0, int tx0, uint4& ent) -> uint32_t {
+    const uint32_t q = rec.x & 0x0fffffffu;
+    if (q >= static_cast<uint32_t>(Lq) || static_cast<int>(rec.x >> 28) != tl) return NS;
+    // origin + 1 (0 .. H, 0 .. W): row / column 0 holds the footprints that hang over the edge
+    int oy, ox;
+    float ly, lx;
+    const bool any = footprint_origin(__uint_as_float(rec.z), __uint_as_float(rec.w), H, W, oy, ox, ly, lx);
+    const int sy = oy - ty0, sx = ox - tx0;
+    if (!any || sy < 0 || sy > TW || sx < 0 || sx > TW) return NS;
+    ent = make_uint4(q, rec.y, __float_as_uint(lx), __float_as_uint(ly));
+    return static_cast<uint32_t>(sy * (TW + 1) + sx);
+  };
+  // the lane group's slot list [e0, e1) of `entries`: one grad_out row per entry, four corner sums
+  const auto walk = [&](const uint4* entries, uint32_t e0, uint32_t e1) {
+    for (uint32_t e = e0; e < e1; e += U) {
+      float w[U][4], rv[U][NCH][CPL];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const uint4 en = entries[min(e + u, e1 - 1)];
+        const float a = e + u < e1 ? __uint_as_float(en.y) : 0.f;  // a repeated row adds nothing
+        const float lx = __uint_as_float(en.z), ly = __uint_as_float(en.w);
+        const float hx = 1.f - lx, hy = 1.f - ly;
+        w[u][0] = a * (hy * hx);
+        w[u][1] = a * (hy * lx);
+        w[u][2] = a * (ly * hx);
+        w[u][3] = a * (ly * lx);
+        const uint32_t row = __umul24(en.x, q_stride) + pl * 16u;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j)
+          Chunk<VT>::unpack(
+              __builtin_bit_cast(uint4, static_cast<u32x4>(__builtin_amdgcn_raw_buffer_load_b128(
+                                            gres, static_cast<int>(row + j * PL * 16), 0, 0))),
+              rv[u][j]);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int c4 = 0; c4 < 4; ++c4)
+#pragma unroll
+          for (int j = 0; j < NCH; ++j)
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) acc[c4][j][c] = fmaf(w[u][c4], rv[u][j][c], acc[c4][j][c]);
+    }
+  };
+  // Rounds of RR * NT records of one patch, from record `base` on: count per slot, scan, fill,
+  // walk.  The two count arrays alternate between rounds and the next round's counts are
+  // cleared during the scan, so a wave that has finished its walk starts on the next round's
+  // records while slower waves still walk (no barrier at the end of a round).  cnt2 is all zero
+  // on entry; on return one of its halves is not.
+  const auto rounds = [&](auto rr_c, uint32_t base, uint32_t total, uint4* entries,
+                          const uint32_t* rf, const uint32_t* rb, int n_runs, int ty0, int tx0) {
+    constexpr int RR = decltype(rr_c)::value;
+    int parity = 0;
+    for (; base < total; base += RR * NT, parity ^= 1) {
+      uint32_t* cnt = cnt2 + parity * NS;
+      uint4 ent[RR];       // {query, weight, lx, ly}
+      uint32_t slot[RR];   // NS = not in this patch
+      uint4 recs[RR];
+#pragma unroll
+      for (int j = 0; j < RR; ++j)
+        recs[j] = load_record(rf, rb, n_runs, min(base + j * NT + threadIdx.x, total - 1));
+#pragma unroll
+      for (int j = 0; j < RR; ++j) {
+        slot[j] = base + j * NT + threadIdx.x < total ? slot_of(recs[j], ty0, tx0, ent[j]) : NS;
+        if (slot[j] < NS) atomicAdd(&cnt[slot[j]], 1u);
+      }
+      MSDA_STAMP(1);
+      __syncthreads();
+      MSDA_STAMP(2);
+      if (threadIdx.x < NS) {  // exclusive scan of the slot counts by wave 0; cnt becomes the cursor
+        const uint32_t c = cnt[threadIdx.x];
+        const uint32_t incl = wave_inclusive_scan(c);
+        start[threadIdx.x] = incl - c;
+        cnt[threadIdx.x] = incl - c;
+        if (threadIdx.x == NS - 1) start[NS] = incl;
+        cnt2[(parity ^ 1) * NS + threadIdx.x] = 0;  // the next round's counts
+      }
+      __syncthreads();
+      MSDA_STAMP(3);
+#pragma unroll
+      for (int j = 0; j < RR; ++j)
+        if (slot[j] < NS) entries[atomicAdd(&cnt[slot[j]], 1u)] = ent[j];
+      MSDA_STAMP(4);
+      __syncthreads();
+      MSDA_STAMP(5);
+      walk(entries, start[pg], start[pg + 1]);
+      MSDA_STAMP(6);
+    }
+  };
+  // The four corner sums of every slot meet at their output positions: lane group pg also owns
+  // output position (pg / 8, pg % 8) of the patch (when both are < 7), which adds corner (dy, dx)
+  // of slot (y + 1 - dy, x + 1 - dx).  `comb`: NS rows of D floats.  Starts with a barrier.
+  const auto combine_store = [&](float4* comb, int ty0, int tx0) {
+    constexpr int F4 = D / 4;            // float4 per row
+    constexpr int F4L = NCH * CPL / 4;   // float4 per lane and row: the lane's channels, in order
+    const int py = pg >> 3, px = pg & 7;
+    float out[NCH][CPL];
 #pragma unroll
     for (int j = 0; j < NCH; ++j)
 #pragma unroll
-      for (int c = 0; c < CPL; ++c) acc[c4][j][c] = 0.f;
-
-  int parity = 0;
-  for (uint32_t base = 0; base < total; base += R, parity ^= 1) {
-    uint32_t* cnt = cnt2 + parity * NS;
-    // ---- A: this thread's records of the round: origin slot, count ----
-    uint4 ent[RPT];       // {query, weight, lx, ly}
-    uint32_t slot[RPT];   // NS = not in this patch
-    uint4 recs[RPT];
+      for (int c = 0; c < CPL; ++c) out[j][c] = 0.f;
 #pragma unroll
-    for (int j = 0; j < RPT; ++j) {
-      const uint32_t i = min(base + j * NT + threadIdx.x, total - 1);
-      int lo = 0, hi = n_runs;  // run_first[lo] <= i < run_first[hi]
-      while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if (run_first[mid] <= i) lo = mid; else hi = mid;
-      }
-      recs[j] = slab_records[run_base[lo] + (i - run_first[lo])];
-    }
-#pragma unroll
-    for (int j = 0; j < RPT; ++j) {
-      const uint32_t i = base + j * NT + threadIdx.x;
-      slot[j] = NS;
-      const uint4 rec = recs[j];
-      const uint32_t q = rec.x & 0x0fffffffu;
-      // (a query index outside the tensor or another level's record can only come from a
-      // corrupted workspace: dropped before any address is formed from it)
-      if (i < total && q < static_cast<uint32_t>(Lq) && static_cast<int>(rec.x >> 28) == tl) {
-        // origin + 1 (0 .. H, 0 .. W): row / column 0 holds the footprints that hang over the edge
-        int oy, ox;
-        float ly, lx;
-        const bool any = footprint_origin(__uint_as_float(rec.z), __uint_as_float(rec.w), TL.H,
-                                          TL.W, oy, ox, ly, lx);
-        const int sy = oy - ty0, sx = ox - tx0;
-        if (any && sy >= 0 && sy <= TW && sx >= 0 && sx <= TW) {
-          slot[j] = static_cast<uint32_t>(sy * (TW + 1) + sx);
-          ent[j] = make_uint4(q, rec.y, __float_as_uint(lx), __float_as_uint(ly));
-          atomicAdd(&cnt[slot[j]], 1u);
-        }
-      }
-    }
-    MSDA_STAMP(1);
-    __syncthreads();
-    MSDA_STAMP(2);
-    // ---- B: exclusive scan of the 64 slot counts by wave 0; cnt becomes the cursor ----
-    if (threadIdx.x < NS) {
-      const uint32_t c = cnt[threadIdx.x];
-      const uint32_t incl = wave_inclusive_scan(c);
-      start[threadIdx.x] = incl - c;
-      cnt[threadIdx.x] = incl - c;
-      if (threadIdx.x == NS - 1) start[NS] = incl;
-      cnt2[(parity ^ 1) * NS + threadIdx.x] = 0;  // the next round's counts
-    }
-    __syncthreads();
-    MSDA_STAMP(3);
-    // ---- C: fill ----
-#pragma unroll
-    for (int j = 0; j < RPT; ++j)
-      if (slot[j] < NS) entries[atomicAdd(&cnt[slot[j]], 1u)] = ent[j];
-    MSDA_STAMP(4);
-    __syncthreads();
-    MSDA_STAMP(5);
-    // ---- D: walk the list of this lane group's origin slot ----
-    {
-      const uint32_t e0 = start[pg], e1 = start[pg + 1];
-      for (uint32_t e = e0; e < e1; e += U) {
-        float w[U][4], rv[U][NCH][CPL];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const uint4 en = entries[min(e + u, e1 - 1)];
-          const float a = e + u < e1 ? __uint_as_float(en.y) : 0.f;  // a repeated row adds nothing
-          const float lx = __uint_as_float(en.z), ly = __uint_as_float(en.w);
-          const float hx = 1.f - lx, hy = 1.f - ly;
-          w[u][0] = a * (hy * hx);
-          w[u][1] = a * (hy * lx);
-          w[u][2] = a * (ly * hx);
-          w[u][3] = a * (ly * lx);
-          const uint32_t row = __umul24(en.x, q_stride) + pl * 16u;
-#pragma unroll
-          for (int j = 0; j < NCH; ++j)
-            Chunk<VT>::unpack(__builtin_bit_cast(uint4, static_cast<u32x4>(__builtin_amdgcn_raw_buffer_load_b128(
-                                  gres, static_cast<int>(row + j * PL * 16), 0, 0))),
-                              rv[u][j]);
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-#pragma unroll
-          for (int c4 = 0; c4 < 4; ++c4)
-#pragma unroll
-            for (int j = 0; j < NCH; ++j)
-#pragma unroll
-              for (int c = 0; c < CPL; ++c) acc[c4][j][c] = fmaf(w[u][c4], rv[u][j][c], acc[c4][j][c]);
-      }
-    }
-    MSDA_STAMP(6);
-  }
-  MSDA_STAMP_FLUSH(1);
-
-  // ---- the four corner sums of every slot meet at their output positions ----
-  // lane group pg also owns output position (pg / 8, pg % 8) of the patch (when both are < 7)
-  float4* comb = reinterpret_cast<float4*>(entries);  // [slot][D / 4] floats
-  constexpr int F4 = D / 4;            // float4 per row
-  constexpr int F4L = NCH * CPL / 4;   // float4 per lane and row: the lane's channels, in order
-  const int py = pg >> 3, px = pg & 7;
-  float out[NCH][CPL];
-#pragma unroll
-  for (int j = 0; j < NCH; ++j)
-#pragma unroll
-    for (int c = 0; c < CPL; ++c) out[j][c] = 0.f;
-#pragma unroll
-  for (int c4 = 0; c4 < 4; ++c4) {
-    __syncthreads();  // the last walk (c4 = 0) / the reads of the corner before are done
-#pragma unroll
-    for (int k = 0; k < F4L; ++k) {
-      const int j = (k * 4) / CPL, c = (k * 4) % CPL;
-      comb[pg * F4 + pl * F4L + k] =
-          make_float4(acc[c4][j][c], acc[c4][j][c + 1], acc[c4][j][c + 2], acc[c4][j][c + 3]);
-    }
-    __syncthreads();
-    const int sy = py + 1 - (c4 >> 1), sx = px + 1 - (c4 & 1);  // 0 .. 8; 8 only for unused groups
-    if (py < TW && px < TW) {
+    for (int c4 = 0; c4 < 4; ++c4) {
+      __syncthreads();  // the last walk (c4 = 0) / the reads of the corner before are done
 #pragma unroll
       for (int k = 0; k < F4L; ++k) {
-        const float4 v = comb[(sy * (TW + 1) + sx) * F4 + pl * F4L + k];
         const int j = (k * 4) / CPL, c = (k * 4) % CPL;
-        out[j][c] += v.x;
-        out[j][c + 1] += v.y;
-        out[j][c + 2] += v.z;
-        out[j][c + 3] += v.w;
+        comb[pg * F4 + pl * F4L + k] =
+            make_float4(acc[c4][j][c], acc[c4][j][c + 1], acc[c4][j][c + 2], acc[c4][j][c + 3]);
+      }
+      __syncthreads();
+      const int sy = py + 1 - (c4 >> 1), sx = px + 1 - (c4 & 1);  // 0 .. 8; 8 only for unused groups
+      if (py < TW && px < TW) {
+#pragma unroll
+        for (int k = 0; k < F4L; ++k) {
+          const float4 v = comb[(sy * (TW + 1) + sx) * F4 + pl * F4L + k];
+          const int j = (k * 4) / CPL, c = (k * 4) % CPL;
+          out[j][c] += v.x;
+          out[j][c + 1] += v.y;
+          out[j][c + 2] += v.z;
+          out[j][c + 3] += v.w;
+        }
       }
     }
-  }
-  if (py >= TW || px >= TW) return;
-  const int yy = ty0 + py, xx = tx0 + px;
-  if (yy >= TL.H || xx >= TL.W) return;
-  const int64_t pos = TL.start + static_cast<int64_t>(yy) * TL.W + xx;
-  if (pos >= S) return;
-  // the lane's channels are chunks pl, pl + 4, ... of the row, as everywhere in these kernels
-  char* dst = reinterpret_cast<char*>(grad_value) +
-              (((static_cast<int64_t>(b) * S + pos) * M + m) * D) * sizeof(VT) + pl * 16;
+    const int yy = ty0 + py, xx = tx0 + px;
+    if (py >= TW || px >= TW || yy >= H || xx >= W) return;
+    const int64_t pos = lstart + static_cast<int64_t>(yy) * W + xx;
+    if (pos >= S) return;
+    // the lane's channels are chunks pl, pl + 4, ... of the row, as everywhere in these kernels
+    char* dst = reinterpret_cast<char*>(grad_value) +
+                (((static_cast<int64_t>(b) * S + pos) * M + m) * D) * sizeof(VT) + pl * 16;
 #pragma unroll
-  for (int j = 0; j < NCH; ++j) Chunk<VT>::store(dst + j * PL * 16, out[j]);
+    for (int j = 0; j < NCH; ++j) Chunk<VT>::store(dst + j * PL * 16, out[j]);
+  };
+  const auto patch_origin = [&](int k, int& ty0, int& tx0) {
+    const int r = t_first + k - lvls.tstart[tl];
+    const int row = r / txl;
+    ty0 = row * TW;
+    tx0 = (r - row * txl) * TW;
+  };
+
+  if (nt == 1) {
+    // one (record-heavy) patch: rounds of R records through all the regions
+    int ty0, tx0;
+    patch_origin(0, ty0, tx0);
+    const uint32_t* rf = run_tab;
+    const int n_runs = static_cast<int>(n_runs_s[0]);
+    clear_acc();
+    rounds(std::integral_constant<int, RPT>{}, 0u, rf[n_runs], region, rf, rf + plan.n_qblocks + 1,
+           n_runs, ty0, tx0);
+    combine_store(reinterpret_cast<float4*>(region), ty0, tx0);
+    MSDA_STAMP(7);
+    MSDA_STAMP_FLUSH(1);
+    return;
+  }
+
+  // ---- several patches: the first R0 records of each are taken together ----
+  {
+    uint4 recs[T][RPT0], ent[T][RPT0];
+    uint32_t slot[T][RPT0];
+#pragma unroll
+    for (int k = 0; k < T; ++k) {
+      const uint32_t* rf = run_tab + k * tab_words;
+      const int n = k < nt ? static_cast<int>(n_runs_s[k]) : 0;
+      const uint32_t total = n > 0 ? rf[n] : 0u;
+#pragma unroll
+      for (int j = 0; j < RPT0; ++j) {
+        slot[k][j] = total;  // (kept until the loads have been issued)
+        if (total > 0)
+          recs[k][j] = load_record(rf, rf + plan.n_qblocks + 1, n, min(j * NT + threadIdx.x, total - 1));
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < T; ++k) {
+      int ty0, tx0;
+      patch_origin(k, ty0, tx0);
+#pragma unroll
+      for (int j = 0; j < RPT0; ++j) {
+        const uint32_t total = slot[k][j];
+        slot[k][j] = NS;
+        if (j * NT + threadIdx.x < total) {
+          slot[k][j] = slot_of(recs[k][j], ty0, tx0, ent[k][j]);
+          if (slot[k][j] < NS) atomicAdd(&cntA[k * NS + slot[k][j]], 1u);
+        }
+      }
+    }
+    __syncthreads();
+    if (wave < nt) {  // wave k: exclusive scan of patch k's slot counts; cntA becomes the cursor
+      const uint32_t c = cntA[wave * NS + lane];
+      const uint32_t incl = wave_inclusive_scan(c);
+      startA[wave * (NS + 1) + lane] = incl - c;
+      cntA[wave * NS + lane] = incl - c;
+      if (lane == NS - 1) startA[wave * (NS + 1) + NS] = incl;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < T; ++k)
+#pragma unroll
+      for (int j = 0; j < RPT0; ++j)
+        if (slot[k][j] < NS)
+          region[k * R0 + atomicAdd(&cntA[k * NS + slot[k][j]], 1u)] = ent[k][j];
+    __syncthreads();
+  }
+  MSDA_STAMP(1);
+  for (int k = 0; k < nt; ++k) {
+    int ty0, tx0;
+    patch_origin(k, ty0, tx0);
+    const uint32_t* rf = run_tab + k * tab_words;
+    const int n_runs = static_cast<int>(n_runs_s[k]);
+    const uint32_t total = n_runs > 0 ? rf[n_runs] : 0u;
+    clear_acc();
+    walk(region + k * R0, startA[k * (NS + 1) + pg], startA[k * (NS + 1) + pg + 1]);
+    if (total > R0) {  // (uniform) the rest of a patch with more records, R0 per round, in its own region
+      __syncthreads();  // every wave has walked the first round: the region is free
+      rounds(std::integral_constant<int, RPT0>{}, static_cast<uint32_t>(R0), total, region + k * R0, rf,
+             rf + plan.n_qblocks + 1, n_runs, ty0, tx0);
+      __syncthreads();  // all walks done before the counters are cleared for the next user
+      if (threadIdx.x < 2 * NS) cnt2[threadIdx.x] = 0;
+    }
+    MSDA_STAMP(6);
+    combine_store(reinterpret_cast<float4*>(region + k * R0), ty0, tx0);
+    MSDA_STAMP(7);
+  }
+  MSDA_STAMP_FLUSH(1);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2068,7 +2208,7 @@ inline bool make_bin_plan(int N, int S, int M, int D, int Lq, int L, int P, int 
     if (ok && total == S) {
       nt2d[1] = nt[1];
       // the origin kernel keeps four corner sums of a row in registers: rows of up to 32 channels
-      if (MSDA_TILE_ORIGIN && !det && small && D <= 32) nt2d[0] = nt[0];
+      if (MSDA_TILE_ORIGIN && !det && small && D <= 32 && L <= kOriginMaxLevels) nt2d[0] = nt[0];
     }
   }
   // virtual queries per workgroup (split rows: always 128, one kernel variant fewer) and the
@@ -2243,22 +2383,57 @@ inline int64_t tuned_backward_workspace_bytes(int N, int S, int M, int D, int Lq
 }
 
 // (the plan picks 7 x 7 patches only for rows the origin kernel is built for)
-// lanes per origin slot of the origin kernel: 8 where a row has 8 chunks (fp32, 32 channels)
-#ifndef MSDA_TO_PL8
-#define MSDA_TO_PL8 0
-#endif
 #ifndef MSDA_TO_LDS_PAD
 #define MSDA_TO_LDS_PAD 0  // diagnostic builds: unused LDS, to lower the number of resident workgroups
 #endif
-template <typename VT, int GG>
-constexpr int origin_lanes() { return MSDA_TO_PL8 && GG == 8 ? 8 : 4; }
+// patches per workgroup on the fine levels (1: never more than one)
+#ifndef MSDA_TO_FUSE
+#define MSDA_TO_FUSE kOriginMaxFuse
+#endif
 
+// Levels and patch groups of the origin kernel's launch.  A level's patches are taken
+// kOriginMaxFuse per workgroup when a patch is expected to hold no more records than the fused
+// first round takes (every level receives about the same number of records — Lq * P * 1.31 per
+// head — so the patches of a fine level hold few), and when the run tables of the patches stay
+// within 8 KB of LDS; else one per workgroup.
+inline OriginLevels make_origin_levels(const int64_t* levels_host, int L, int Lq, int P,
+                                       const BinPlan& plan) {
+  OriginLevels o{};
+  int run = 0, pos = 0, least = INT32_MAX;
+  for (int l = 0; l < L; ++l) {
+    o.H[l] = static_cast<int>(levels_host[2 * l]);
+    o.W[l] = static_cast<int>(levels_host[2 * l + 1]);
+    o.start[l] = pos;
+    pos += o.H[l] * o.W[l];
+    o.tx[l] = (o.W[l] + 6) / 7;
+    o.tstart[l] = run;
+    const int n = o.tx[l] * ((o.H[l] + 6) / 7);
+    run += n;
+    least = n < least ? n : least;
+  }
+  o.tstart[L] = run;
+  int cap = 2048 / (2 * plan.n_qblocks + 1);
+  cap = cap < 1 ? 1 : cap > MSDA_TO_FUSE ? MSDA_TO_FUSE : cap;
+  (void)least;
+  const double per_level = static_cast<double>(Lq) * P * 1.31;  // records of a level, per head
+  int groups = 0;
+  for (int l = 0; l < L; ++l) {
+    const int n = o.tstart[l + 1] - o.tstart[l];
+    const int per = per_level / n <= 0.8 * 256 * kOriginFuseRecords ? cap : 1;
+    o.per[l] = per;
+    o.gstart[l] = groups;
+    groups += (n + per - 1) / per;
+  }
+  o.gstart[L] = groups;
+  return o;
+}
+
+// (the plan picks 7 x 7 patches only for rows the origin kernel is built for)
 template <typename VT, int GG, int RR, int UU, typename... Args>
 inline void launch_tile_origin(Launches& run, dim3 grid, size_t lds_bytes, hipStream_t stream,
                                Args... args) {
   if constexpr (GG * Chunk<VT>::kCPL <= 32) {
-    constexpr int PL = origin_lanes<VT, GG>();
-    run((bwd_tile_origin_kernel<VT, GG, RR, UU, PL>), grid, dim3(64 * PL), lds_bytes, stream, args...);
+    run((bwd_tile_origin_kernel<VT, GG, RR, UU>), grid, dim3(256), lds_bytes, stream, args...);
   } else {
     run.rc = static_cast<int>(hipErrorInvalidValue);
   }
@@ -2321,12 +2496,20 @@ int tuned_backward_typed(const void* grad_out, const void* value, const int64_t*
     constexpr int RPT = 2;
     const size_t tlds = 4 * 256 * static_cast<size_t>(RPT) * 8 + (3 * TSz + 1) * 4 +
                         (2 * static_cast<size_t>(plan.n_qblocks) + 1) * 4;
-    // by origin: 16-byte entries of a round or the corner exchange (64 rows of D floats)
-    constexpr size_t kRowF32 = static_cast<size_t>(Chunk<VT>::kCPL) * 4;  // bytes of a chunk as floats
-    const size_t oex = static_cast<size_t>(64) * G * kRowF32;
-    const size_t oent = static_cast<size_t>(64) * (MSDA_TO_PL8 && G == 8 ? 8 : 4) * MSDA_TO_RPT * 16;
-    const size_t olds = (oent > oex ? oent : oex) + (3 * TSz + 1) * 4 +
-                        (2 * static_cast<size_t>(plan.n_qblocks) + 1) * 4 + MSDA_TO_LDS_PAD;
+    // by origin: entry regions, slot counters and list starts, run tables of the patches of a
+    // workgroup (see the kernel)
+    OriginLevels olv{};
+    dim3 ogrid = tgrid;
+    size_t olds = 0;
+    if (plan.tile2d && plan.tw == 7) {
+      olv = make_origin_levels(levels_host, L, Lq, P, plan);
+      int fuse = 1;
+      for (int l = 0; l < L; ++l) fuse = olv.per[l] > fuse ? olv.per[l] : fuse;
+      ogrid = dim3(static_cast<unsigned>(olv.gstart[L]) * M, N);
+      olds = static_cast<size_t>(kOriginMaxFuse) * 256 * kOriginFuseRecords * 16 +
+             static_cast<size_t>(kOriginMaxFuse) * (64 + 65) * 4 + (2 * 64 + 65) * 4 +
+             static_cast<size_t>(fuse) * (2 * static_cast<size_t>(plan.n_qblocks) + 1) * 4 + MSDA_TO_LDS_PAD;
+    }
     // reproducible form: two entry arrays of 4 * 512, one count array
     const size_t dlds = 2 * 4 * 512 * 8 + (2 * TSz + 1) * 4 +
                         (2 * static_cast<size_t>(plan.n_qblocks) + 1) * 4;
@@ -2337,10 +2520,10 @@ int tuned_backward_typed(const void* grad_out, const void* value, const int64_t*
                      g_copy ? 1 : 0)
 #define MSDA_TILE_ORIGIN_K(GG, RR, UU)                                                           \
   launch_tile_origin<VT, GG, RR, UU>(                                                            \
-      run, tgrid, olds, stream,                                                                  \
-      g_copy ? static_cast<const VT*>(g_copy) : static_cast<const VT*>(grad_out), shapes, lsi,   \
+      run, ogrid, olds, stream,                                                                  \
+      g_copy ? static_cast<const VT*>(g_copy) : static_cast<const VT*>(grad_out),                \
       static_cast<const uint4*>(records), static_cast<const uint2*>(dir),                        \
-      static_cast<VT*>(grad_value), S, M, Lq, L, plan, g_copy ? 1 : 0)
+      static_cast<VT*>(grad_value), S, M, Lq, L, plan, g_copy ? 1 : 0, olv)
 #define MSDA_TILE_DET(GG)                                                                        \
   run((bwd_tile_gather_det_kernel<VT, GG>), tgrid, dim3(256), dlds, stream,                      \
       g_copy ? static_cast<const VT*>(g_copy) : static_cast<const VT*>(grad_out), shapes, lsi,   \
