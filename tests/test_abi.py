@@ -149,8 +149,9 @@ def test_workspace_bytes():
     r256 = lambda x: -(-x // 256) * 256
     tiles7 = 19 * 37 + 10 * 19 + 5 * 10
     base8 = ws(n, s, m, d, s, l, p, _lib.F32, _lib.F32, 0)  # 672 runs of 64 = as many 8 x 8 patches
+    # (the origin kernel reads grad_out as given: no per-head copy in the workspace)
     assert ws_h(n, s, m, d, s, l, p, _lib.F32, _lib.F32, 0, host) - base8 == (
-        r256(n * m * qblocks * tiles7 * 8) - r256(dir_bytes))
+        r256(n * m * qblocks * tiles7 * 8) - r256(dir_bytes) - g_copy_bytes)
     assert ws_h(n, s, m, d, s, l, p, _lib.F32, _lib.F32, det, host) == base8
     assert ws_h(n, s, m, 64, s, l, p, _lib.F32, _lib.F32, 0, host) == ws(n, s, m, 64, s, l, p, _lib.F32, _lib.F32, 0)
     # ragged extents (3 levels of 20x24, 10x12, 5x6: 12+4+1 patches of 7 x 7, 9+4+1 of 8 x 8,
@@ -160,7 +161,7 @@ def test_workspace_bytes():
     base = ws(1, s2, m, d, s2, l, p, _lib.F32, _lib.F32, 0)
     qb2 = -(-s2 // 192)
     assert (ws_h(1, s2, m, d, s2, l, p, _lib.F32, _lib.F32, 0, ragged) - base
-            == r256(m * qb2 * 17 * 8) - r256(m * qb2 * 10 * 8))
+            == r256(m * qb2 * 17 * 8) - r256(m * qb2 * 10 * 8) - m * s2 * d * 4)
     assert (ws_h(1, s2, m, d, s2, l, p, _lib.F32, _lib.F32, det, ragged) - base
             == r256(m * qb2 * 14 * 8) - r256(m * qb2 * 10 * 8))
     wrong = (ctypes.c_int64 * 6)(20, 24, 10, 12, 5, 7)
@@ -288,7 +289,7 @@ def test_workspace_reflects_queries_per_workgroup():
         blocks = -(-lq // qb)
         dir_b = (n * m * blocks * tiles * 8 + 255) // 256 * 256
         rec_b = n * m * blocks * (qb * l * p * 4) * 16
-        return dir_b + rec_b + n * m * lq * d * esize
+        return dir_b + rec_b  # (7 x 7 patches: no per-head copy of grad_out)
 
     def got(n, m, d, dtype, levels, p):
         s = sum(h * w for h, w in levels)

@@ -232,6 +232,10 @@ __host__ __device__ constexpr int query_lanes(int G) { return (MSDA_K3_WIDE && G
 #ifndef MSDA_K3_LDS_EMIT
 #define MSDA_K3_LDS_EMIT 1
 #endif
+// diagnostic builds: unused LDS in the query kernel, to lower the number of resident workgroups
+#ifndef MSDA_K3_LDS_PAD
+#define MSDA_K3_LDS_PAD 0
+#endif
 // minimum waves per SIMD the query kernel's register allocation must allow
 #ifndef MSDA_K3_MINWAVES
 #define MSDA_K3_MINWAVES 1
@@ -408,8 +412,7 @@ __device__ __forceinline__ void load_point_near(const LT* __restrict__ loc_wg,
 
 struct EmitCtx {
   uint4* records;      // this workgroup's record region
-  uint32_t* tile_off;  // LDS: exclusive prefix of records per tile inside the region
-  uint32_t* tile_cnt;  // LDS: running rank per tile
+  uint32_t* tile_cur;  // LDS: per tile, where its next record goes inside the region
   BinPlan plan;        // by value: a pointer to the kernel argument would force it into scratch
   const TileMap* tm;
   uint4* lds_image;    // LDS image of the head of the region (null: records go out directly)
@@ -465,7 +468,7 @@ __device__ __forceinline__ void emit_records(const Footprint<float>& f, const Le
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       if (keep[j]) {
-        const uint32_t at = emit.tile_off[tiles[j]] + atomicAdd(&emit.tile_cnt[tiles[j]], 1u);
+        const uint32_t at = atomicAdd(&emit.tile_cur[tiles[j]], 1u);
         if (at < emit.lds_cap) {
           emit.lds_image[at] = rec;  // leaves the workgroup later, as part of one linear copy
         } else if (at < emit.plan.region) {  // always true: a bug stays in the region
@@ -793,9 +796,10 @@ __global__ __launch_bounds__(256, MSDA_K3_MINWAVES) void bwd_query_kernel(
   const uint32_t headb = static_cast<uint32_t>(m) * (head_major ? S : 1) * D * sizeof(VT);
   // LDS: [tile counters | tile offsets] (binned mode), staged points, parked points (KPC > 0)
   const int stage_total = GPB * group_stride_slots(LPB, SL);
-  const int tile_slots = MODE == 1 ? (2 * plan.n_tiles + 3) / 4 : 0;  // 16-byte slots
+  // one word per tile (+ 1): record count, then (scanned in place) offset inside the region,
+  // then the cursor the records are placed with
+  const int tile_slots = MODE == 1 ? (plan.n_tiles + 1 + 3) / 4 : 0;  // 16-byte slots
   uint32_t* tile_cnt = reinterpret_cast<uint32_t*>(lds);
-  uint32_t* tile_off = tile_cnt + plan.n_tiles;
   uint4* stage = lds + tile_slots;
   EmitCtx emit{};
 
@@ -903,18 +907,17 @@ __global__ __launch_bounds__(256, MSDA_K3_MINWAVES) void bwd_query_kernel(
     }
     __syncthreads();
     MSDA_STAMP(3);  // count pass (waits for the point loads)
-    // directory row of this workgroup: (offset, count) per tile, then ranks restart from 0
+    // directory row of this workgroup: (offset, count) per tile; the offsets then serve as the
+    // cursors of the emit pass
     const int64_t slab = static_cast<int64_t>(b) * M + m;
     uint2* dir_row = dir + (slab * plan.n_qblocks + qblock) * plan.n_tiles;
-    for (int t = threadIdx.x; t < plan.n_tiles; t += 256) tile_off[t] = tile_cnt[t];
-    const uint32_t n_records = block_exclusive_scan(tile_off, plan.n_tiles, scan_tmp);
-    for (int t = threadIdx.x; t < plan.n_tiles; t += 256) {
-      dir_row[t] = make_uint2(tile_off[t], tile_cnt[t]);
-      tile_cnt[t] = 0;
-    }
+    const uint32_t n_records = block_exclusive_scan(tile_cnt, plan.n_tiles, scan_tmp);
+    if (threadIdx.x == 0) tile_cnt[plan.n_tiles] = n_records;
+    __syncthreads();
+    for (int t = threadIdx.x; t < plan.n_tiles; t += 256)
+      dir_row[t] = make_uint2(tile_cnt[t], tile_cnt[t + 1] - tile_cnt[t]);
     emit.records = records + (slab * plan.n_qblocks + qblock) * static_cast<int64_t>(plan.region);
-    emit.tile_off = tile_off;
-    emit.tile_cnt = tile_cnt;
+    emit.tile_cur = tile_cnt;
     emit.plan = plan;
     emit.tm = &tm;
     emit.lds_image = nullptr;
@@ -949,7 +952,7 @@ __global__ __launch_bounds__(256, MSDA_K3_MINWAVES) void bwd_query_kernel(
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             if ((desc >> j) & 1u) {
-              const uint32_t at = tile_off[tiles[j]] + atomicAdd(&tile_cnt[tiles[j]], 1u);
+              const uint32_t at = atomicAdd(&tile_cnt[tiles[j]], 1u);
               if (at < emit.lds_cap) {
                 emit.lds_image[at] = rec;  // leaves the workgroup later, as part of one linear copy
               } else if (at < plan.region) {  // always true: a bug stays in the region
@@ -2156,13 +2159,17 @@ inline bool all_aligned16(std::initializer_list<const void*> ps) {
 inline int row_split(int LP) { return MSDA_K3_PRE && LP > 16 && LP <= 32 && LP % 2 == 0 ? 2 : 1; }
 
 // LP: points per virtual query
+#ifndef MSDA_K3_QB
+#define MSDA_K3_QB 0  // experiment builds: force 128 or 192 queries per workgroup (0: choose)
+#endif
 inline int choose_qb(int G, int LP, int64_t n_tiles) {
   if (!MSDA_K3_PRE || G == 0 || LP > 16) return 192;
+  if (MSDA_K3_QB) return MSDA_K3_QB;
   const int GQ = query_lanes(G), GPB = 256 / GQ;
   const int kpc = GQ == 4 ? (LP <= 12 ? 3 : 4) : 2;
   const auto resident = [&](int qb) {
     const int64_t lds = static_cast<int64_t>(GPB) * group_stride_slots(LP, stage_slots(kStageBwdBinned)) * 16 +
-                        (2 * n_tiles + 3) / 4 * 16 + static_cast<int64_t>(qb / GPB - 1) * kpc * 3 * 1024;
+                        (n_tiles + 4) / 4 * 16 + static_cast<int64_t>(qb / GPB - 1) * kpc * 3 * 1024;
     return (160 * 1024) / (lds + 2560);  // (+ static arrays: 1.9 KB, and allocation granularity)
   };
   return resident(192) < 3 && resident(128) > resident(192) ? 128 : 192;
@@ -2363,8 +2370,11 @@ inline int tuned_forward(const void* value, const int64_t* shapes, const int64_t
 }
 
 // bytes of the per-head grad_out copy at the end of the binned backward's workspace
-inline size_t g_copy_bytes(int N, int M, int D, int Lq, int dtype_val) {
-  if (!MSDA_G_COPY) return 0;
+// (the position-based tile kernels only: they fetch a row once per corner, 3-4 times per
+// record, and the copy pays for itself — tile kernel 1.29 -> 1.08 ms; the origin kernel fetches a
+// row once per record and runs 0.03 ms faster, with 352 MB less workspace, from grad_out as given)
+inline size_t g_copy_bytes(int N, int M, int D, int Lq, int dtype_val, const BinPlan& plan) {
+  if (!MSDA_G_COPY || (plan.tile2d && plan.tw == 7)) return 0;
   return static_cast<size_t>(N) * M * Lq * D * (dtype_val == 0 ? 4 : 2);
 }
 
@@ -2376,7 +2386,7 @@ inline int64_t tuned_backward_workspace_bytes(int N, int S, int M, int D, int Lq
   BinPlan plan;
   size_t dir_b, rec_b;
   if (allow_binned && make_bin_plan(N, S, M, D, Lq, L, P, G, levels_host, &plan, &dir_b, &rec_b, det))
-    return static_cast<int64_t>(dir_b + rec_b + g_copy_bytes(N, M, D, Lq, dtype_val));
+    return static_cast<int64_t>(dir_b + rec_b + g_copy_bytes(N, M, D, Lq, dtype_val, plan));
   if (det) return -1;  // reproducible form: binned path only, else the caller's generic gather
   if (dtype_val == 0) return 0;
   return static_cast<int64_t>(N) * S * M * D * 4;  // fp32 accumulation image of grad_value
@@ -2480,12 +2490,14 @@ int tuned_backward_typed(const void* grad_out, const void* value, const int64_t*
   if (binned) {
     uint2* dir = static_cast<uint2*>(workspace);
     uint4* records = reinterpret_cast<uint4*>(static_cast<char*>(workspace) + dir_b);
-    VT* g_copy = MSDA_G_COPY ? reinterpret_cast<VT*>(static_cast<char*>(workspace) + dir_b + rec_b)
+    VT* g_copy = g_copy_bytes(N, M, D, Lq, sizeof(VT) == 4 ? 0 : 2, plan) > 0
+                     ? reinterpret_cast<VT*>(static_cast<char*>(workspace) + dir_b + rec_b)
                              : static_cast<VT*>(nullptr);
     const dim3 qgrid(static_cast<unsigned>(plan.n_qblocks) * M, N);
     const size_t qlds = static_cast<size_t>(GPB) * group_stride_slots(LPB, slots) * 16 +
-                        (static_cast<size_t>(2 * plan.n_tiles + 3) / 4) * 16 +
-                        (kpc ? static_cast<size_t>((plan.qb / GPB - 1) * kpc) * 3 * 256 * 4 : 0);  // parked points
+                        (static_cast<size_t>(plan.n_tiles + 4) / 4) * 16 +
+                        (kpc ? static_cast<size_t>((plan.qb / GPB - 1) * kpc) * 3 * 256 * 4 : 0) +  // parked points
+                        MSDA_K3_LDS_PAD;
     const dim3 tgrid(static_cast<unsigned>(plan.n_tiles) * M, N);
     const size_t TSz = static_cast<size_t>(1) << plan.ts_shift;
     // Rounds of 512 records (2 per thread) and 3 entries per walk step (2 for rows of 16 chunks):
@@ -2549,8 +2561,12 @@ int tuned_backward_typed(const void* grad_out, const void* value, const int64_t*
     if (kpc != 4 || plan.qb != 128 || plan.split != 2) return kNotTuned;                         \
     MSDA_TQB(GG, 4, 128, 2);                                                                     \
   } else {                                                                                       \
-    if (kpc != 3 || plan.qb != 192) return kNotTuned;                                            \
-    MSDA_TQB(GG, 3, 192, 1);                                                                     \
+    if ((kpc != 3 && kpc != 2) || plan.split != 1) return kNotTuned;                             \
+    if (plan.qb == 128) {                                                                        \
+      MSDA_TQB(GG, (query_lanes(GG) == 4 ? 3 : 2), 128, 1);                                      \
+    } else {                                                                                     \
+      MSDA_TQB(GG, (query_lanes(GG) == 4 ? 3 : 2), 192, 1);                                      \
+    }                                                                                            \
   }                                                                                              \
   if (phase & kPhaseGrad) {                                                                      \
     if (det) return kNotTuned;                                                                   \
