@@ -25,7 +25,7 @@ def counters(name):
 
 stats = kernel_stats()
 pmc = {}
-for name in ("FETCH_SIZE", "WRITE_SIZE", "TCC_HIT_sum", "GRBM_GUI_ACTIVE", "SQ_WAVES"):
+for name in ("FETCH_SIZE", "WRITE_SIZE", "TCC_HIT_sum", "GRBM_GUI_ACTIVE", "SQ_WAVES", "SQ_LDS_BANK_CONFLICT"):
     for k, d in counters(name).items():
         pmc.setdefault(k, {}).update(d)
 bench = json.loads(open(f"{out}/bench.json").read().strip().splitlines()[-1])
@@ -62,4 +62,14 @@ with open(f"{out}/summary_{tag}.md", "w") as f:
         if "ta_busy_frac" not in d:
             continue
         f.write(f"| `{k}` | {d['GRBM_GUI_ACTIVE'] / 8:.3e} | {d['ta_busy_frac']:.2f} | {d['l1_accesses_per_clk_per_cu']:.2f} | {d.get('valu_busy_frac', 0):.2f} | {d.get('SQ_INSTS_VALU', 0):.3e} | {d.get('SQ_INSTS_SALU', 0):.3e} | {d.get('SQ_INSTS_LDS', 0):.3e} | {d.get('SQ_INSTS_VMEM_RD', 0):.3e} | {d.get('SQ_INSTS_VMEM_WR', 0):.3e} | {d.get('SQ_WAVES', 0):.0f} |\n")
+    f.write("\n## wave state and LDS per launch (sums over the chip)\n\nWAIT_ANY: wave parked at s_waitcnt or a barrier; WAIT_INST_ANY: wave ready but its instruction cannot issue (the pipeline it needs is busy); LDS bank conflict = conflict cycles / LDS-array cycles; LDS busy = LDS-array cycles per CU / kernel cycles.\n\n| kernel | wave cycles | WAIT_ANY | WAIT_INST_ANY | WAIT_INST_LDS | issuing (ACTIVE_INST_ANY) | LDS bank conflict | LDS busy |\n|---|---|---|---|---|---|---|---|\n")
+    for k, d in pmc.items():
+        if "SQ_WAIT_ANY" not in d or not d.get("SQ_WAVE_CYCLES"):
+            continue
+        wc = d["SQ_WAVE_CYCLES"]
+        cyc = d.get("GRBM_GUI_ACTIVE", 0) / 8
+        d["lds_bank_conflict_frac"] = d["SQ_LDS_BANK_CONFLICT"] / max(d["SQ_LDS_IDX_ACTIVE"], 1)
+        d["lds_busy_frac"] = d["SQ_LDS_IDX_ACTIVE"] / 256 / cyc if cyc else 0
+        f.write(f"| `{k}` | {wc:.3e} | {d['SQ_WAIT_ANY'] / wc:.2f} | {d['SQ_WAIT_INST_ANY'] / wc:.2f} | {d['SQ_WAIT_INST_LDS'] / wc:.3f} | {d['SQ_ACTIVE_INST_ANY'] / wc:.2f} | {d['lds_bank_conflict_frac']:.2f} | {d['lds_busy_frac']:.2f} |\n")
+json.dump(summary, open(f"{out}/summary_{tag}.json", "w"), indent=1)
 print(open(f"{out}/summary_{tag}.md").read())

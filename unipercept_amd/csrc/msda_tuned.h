@@ -1050,14 +1050,16 @@ __global__ __launch_bounds__(256, MSDA_K3_MINWAVES) void bwd_query_kernel(
       const uint32_t slab_bytes = static_cast<uint32_t>(S) * M * D * sizeof(VT);
       const __amdgpu_buffer_rsrc_t vres = __builtin_amdgcn_make_buffer_rsrc(
           const_cast<char*>(vb), 0, static_cast<int>(slab_bytes), 0x00020000);
+      // (the fractions of a point are read from LDS when its rows are consumed, not held in
+      // registers while the loads are in flight)
       struct PointRegs {
-        uint4 orr, fr;
+        int i;
         u32x4 raw[4][NC];
       };
       const auto issue = [&](int i, PointRegs& pr) {
-        pr.orr = r[SL * i + SL - 2];
-        pr.fr = r[SL * i + SL - 1];
-        const uint32_t oraw[4] = {pr.orr.x, pr.orr.y, pr.orr.z, pr.orr.w};
+        const uint4 orr = r[SL * i + SL - 2];
+        pr.i = i;
+        const uint32_t oraw[4] = {orr.x, orr.y, orr.z, orr.w};
 #pragma unroll
         for (int c4 = 0; c4 < 4; ++c4)
 #pragma unroll
@@ -1070,8 +1072,9 @@ __global__ __launch_bounds__(256, MSDA_K3_MINWAVES) void bwd_query_kernel(
       // softmax backward d logit_i = w_i * (g_i - sum_k w_k g_k) once all points are through
       float ka[4] = {0.f, 0.f, 0.f, 0.f}, kg[4] = {0.f, 0.f, 0.f, 0.f};
       const auto consume = [&](const PointRegs& pr, int k) {
-        const float lx = __uint_as_float(pr.fr.x), ly = __uint_as_float(pr.fr.y);
-        const float aW = __uint_as_float(pr.fr.z), aH = __uint_as_float(pr.fr.w);
+        const uint4 fr = r[SL * pr.i + SL - 1];
+        const float lx = __uint_as_float(fr.x), ly = __uint_as_float(fr.y);
+        const float aW = __uint_as_float(fr.z), aH = __uint_as_float(fr.w);
         const float hx = 1.f - lx, hy = 1.f - ly;
         float dot[4];
 #pragma unroll
