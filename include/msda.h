@@ -58,7 +58,9 @@ enum {
    * and grad_attn always do).  Shapes the binned path covers (msda_head_major_supported) keep
    * that path and run a tile kernel that adds every position's contributions in an order fixed
    * by the data (runs in query-block order, rounds made of whole runs, entries sorted per
-   * position): about twice that kernel's time at any size, same workspace.  Other shapes (F64,
+   * position): about 2.5 times the backward's time at any size (measured on MI355X at the
+   * Cityscapes shapes: 2.04 -> 5.15 ms); pass the flag to msda_backward_workspace_bytes too, the
+   * size differs.  Other shapes (F64,
    * head dims without a tuned kernel) use a per-destination gather in a fixed order, O(S * Lq * P)
    * per head and channel — for small problems (gradcheck, debugging) only. */
   MSDA_FLAG_DETERMINISTIC = 1,
@@ -180,10 +182,12 @@ int msda_value_relayout(const void* src, void* dst, const unsigned char* padding
 
 /*
  * Scratch the backward needs, in bytes (0 when none).  The binned grad_value path keeps its
- * scatter records (64 bytes per sampled point, worst case), a tile directory and a per-head
- * copy of grad_out (as large as grad_out) there; the
+ * scatter records (64 bytes per sampled point, worst case) and a tile directory there, and —
+ * without `shapes_host`, with MSDA_FLAG_TILE_1D or MSDA_FLAG_DETERMINISTIC, and for head dims
+ * above 32 channels per four lanes — a per-head copy of grad_out (as large as grad_out); the
  * atomic paths need an fp32 accumulation image of grad_value for 16-bit value dtypes.
- * `shapes_host`: as for msda_backward (the size depends on it); pass the same value to both.
+ * `flags`, `shapes_host`: as for msda_backward (the size depends on them); pass the same values
+ * to both.
  */
 size_t msda_backward_workspace_bytes(int N, int S, int M, int D, int Lq, int L, int P,
                                      int dtype_val, int dtype_loc, int flags,

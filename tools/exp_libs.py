@@ -52,7 +52,7 @@ def run(lib, what):
     if what in ("fwd", "all"):
         rc = lib.msda_forward(vt.data_ptr(), shapes.data_ptr(), lsi.data_ptr(), loc.data_ptr(), attn.data_ptr(), None, out.data_ptr(), n, s, m, d, lq, l, p, dv, dl, HM, st); assert rc == 0, rc
     if what in ("bwd", "all"):
-        nb = lib.msda_backward_workspace_bytes(n, s, m, d, lq, l, p, dv, dl, HM, host)
+        nb = lib.msda_backward_workspace_bytes(n, s, m, d, lq, l, p, dv, dl, HM | int(os.environ.get('XFLAGS', '0')), host)
         if ws is None or ws.numel() < nb: ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
         rc = lib.msda_backward(g.data_ptr(), vt.data_ptr(), shapes.data_ptr(), lsi.data_ptr(), loc.data_ptr(), attn.data_ptr(), None, gv.data_ptr(), gl.data_ptr(), ga.data_ptr(), ws.data_ptr(), ws.numel(), n, s, m, d, lq, l, p, dv, dl, HM | int(os.environ.get('XFLAGS', '0')), host, st); assert rc == 0, rc
 def set_env(spec, on):
