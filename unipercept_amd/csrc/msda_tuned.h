@@ -198,6 +198,57 @@ __device__ __forceinline__ LevelInfo load_level(const int64_t* __restrict__ shap
   return r;
 }
 
+// Query order.  When the queries are the positions of the pyramid itself (the encoder: the levels
+// tile [0, Lq) in order), a workgroup does not take consecutive queries — a piece of one image
+// row, whose sampling points spread over a wide, flat strip of every level — but consecutive
+// queries of a patch-by-patch walk over the levels: patches of kOrderTH x kOrderTW pixels in
+// raster order, row-major inside (patches at the bottom and right edges are cut).  The points of
+// a workgroup then fall into a compact region: the row gathers of the workgroups resident on a
+// CU overlap more, and the scatter records of a query block land in fewer destination tiles, as
+// longer runs.  Which workgroup takes which query changes nothing in the results.  Measured on
+// MI355X (Cityscapes pyramid, fp32): forward 0.80 -> 0.78 ms, backward 2.05 -> 1.97 ms; patches
+// of 8 x 8 to 64 x 8, 16 x 16 and column strips all within 1 % of one another.
+#ifndef MSDA_ORDER_TH
+#define MSDA_ORDER_TH 64
+#endif
+#ifndef MSDA_ORDER_TW
+#define MSDA_ORDER_TW 8
+#endif
+constexpr int kOrderTH = MSDA_ORDER_TH, kOrderTW = MSDA_ORDER_TW;
+
+// Query index of work item `w` in [0, Lq): the patch-order walk above when `enabled` and the
+// levels (LDS table `lv`) tile [0, Lq) exactly, else w itself.  A bijection of [0, Lq) either way.
+__device__ __forceinline__ int order_query(int w, const LevelInfo* lv, int L, int Lq, bool enabled) {
+  if (!enabled) return w;
+  int acc = 0, H = 0, W = 0, start = 0;
+  bool tiled = true, found = false;
+  for (int l = 0; l < L; ++l) {
+    const LevelInfo v = lv[l];
+    const int n = v.H * v.W;
+    tiled = tiled && n > 0 && v.start == acc;
+    if (w >= acc && w < acc + n) {
+      found = true;
+      H = v.H;
+      W = v.W;
+      start = acc;
+    }
+    acc += n;
+  }
+  if (!tiled || acc != Lq || !found) return w;
+  const uint32_t u = static_cast<uint32_t>(w - start);
+  const uint32_t per_row = static_cast<uint32_t>(kOrderTH) * W;  // queries of a full row of patches
+  const uint32_t pr = u / per_row;
+  const uint32_t rem = u - pr * per_row;
+  const uint32_t hr = min(static_cast<uint32_t>(kOrderTH), static_cast<uint32_t>(H) - pr * kOrderTH);
+  const uint32_t per_patch = hr * kOrderTW;  // (the last patch of the row may be narrower)
+  const uint32_t pc = rem / per_patch;
+  const uint32_t rem2 = rem - pc * per_patch;
+  const uint32_t wc = min(static_cast<uint32_t>(kOrderTW), static_cast<uint32_t>(W) - pc * kOrderTW);
+  const uint32_t y = rem2 / wc;
+  const uint32_t x = rem2 - y * wc;
+  return start + static_cast<int>((pr * kOrderTH + y) * W + pc * kOrderTW + x);
+}
+
 // One staged sampling point occupies 2 or 3 16-byte LDS slots (see StageKind):
 //   weights:   the four corner weights, multiplied by the attention weight, 0 for a corner
 //              outside the level (not staged by the binned backward, which never uses them);
@@ -272,6 +323,7 @@ struct BinPlan {
   int phase;        // query kernel: bit 0 = bin the scatter (directory + records), bit 1 = gradients
   int q_per_block;  // (real) queries whose records one region holds: qb / split
   int split;        // virtual queries per query in the query kernel (rows of 17-32 points: 2)
+  int patch_order;  // query kernel, register-resident form: query blocks in patch order (order_query)
 };
 constexpr int kPhaseBin = 1, kPhaseGrad = 2;
 
@@ -528,27 +580,32 @@ __device__ __forceinline__ void stage_chunk(const LevelInfo* lv, const LT* __res
                                             int P, int i_first, int nI, int LPB, uint32_t rowb,
                                             uint32_t headb, PointRows rs, const EmitCtx& emit,
                                             const float* __restrict__ ref = nullptr,
-                                            const float2* row_stats = nullptr, int L = 0) {
+                                            const float2* row_stats = nullptr, int L = 0,
+                                            const int* qidx = nullptr) {
   // points i_first .. i_first + nI - 1 of every query; LDS lists are laid out for LPB points
+  // qidx (LDS, optional): the query index of each of the nq queries, when they are not
+  // q_first, q_first + 1, ... (then Lq * M < 2^24, so rows count from the batch element's first)
   constexpr int SLOTS = stage_slots(KIND);
   const int npts = nq * nI;
   const int stride = group_stride_slots(LPB, SLOTS);
   const float inv_nI = 1.0f / static_cast<float>(nI), inv_P = 1.0f / static_cast<float>(P);
-  const int64_t row0 = (static_cast<int64_t>(b) * Lq + q_first) * M + m;  // first query's row
+  const int q_base = qidx != nullptr ? 0 : q_first;
+  const int64_t row0 = (static_cast<int64_t>(b) * Lq + q_base) * M + m;  // row the offsets count from
   const LT* loc_wg = loc + row0 * rs.loc;
   const LT* attn_wg = attn + row0 * rs.attn;
-  const float* ref_wg = ref == nullptr ? nullptr : ref + (static_cast<int64_t>(b) * Lq + q_first) * L * 2;
+  const float* ref_wg = ref == nullptr ? nullptr : ref + (static_cast<int64_t>(b) * Lq + q_base) * L * 2;
   for (int t = threadIdx.x; t < npts; t += 256) {
     int g, ii, l, p_unused;
     small_divmod(t, nI, inv_nI, g, ii);
     const int i = i_first + ii;
     small_divmod(i, P, inv_P, l, p_unused);
+    const uint32_t qo = qidx != nullptr ? static_cast<uint32_t>(qidx[g]) : static_cast<uint32_t>(g);
     float x, y, a;
-    load_point_near(loc_wg, attn_wg, __umul24(g, M), i, rs, x, y, a);
+    load_point_near(loc_wg, attn_wg, __umul24(qo, M), i, rs, x, y, a);
     if (ref != nullptr)
-      raw_to_point(ref_wg + (__umul24(g, L) + l) * 2u, lv[l], row_stats[g], x, y, a);
-    stage_point<KIND, EMIT>(lv[l], l, x, y, a, q_first + g, stage + (__umul24(g, stride) + SLOTS * ii), rowb,
-                            headb, emit, ref != nullptr);
+      raw_to_point(ref_wg + (__umul24(qo, L) + l) * 2u, lv[l], row_stats[g], x, y, a);
+    stage_point<KIND, EMIT>(lv[l], l, x, y, a, q_base + static_cast<int>(qo),
+                            stage + (__umul24(g, stride) + SLOTS * ii), rowb, headb, emit, ref != nullptr);
   }
 }
 
@@ -572,7 +629,7 @@ __global__ __launch_bounds__(256) void fwd_tuned_kernel(
     const VT* __restrict__ value, const int64_t* __restrict__ shapes,
     const int64_t* __restrict__ lsi, const LT* __restrict__ loc, const LT* __restrict__ attn,
     VT* __restrict__ out, int S, int M, int Lq, int L, int P, int LPB, int head_major,
-    PointRows rs, const float* __restrict__ ref) {
+    PointRows rs, const float* __restrict__ ref, int patch_order) {
   constexpr int CPL = Chunk<VT>::kCPL;
   constexpr int D = G * CPL;
   // one chunk per lane here: two (as in the backward query kernel) measured 20 % slower, the
@@ -591,10 +648,16 @@ __global__ __launch_bounds__(256) void fwd_tuned_kernel(
   const int q0 = (blockIdx.x / M) * GPB;
   const int nq = min(GPB, Lq - q0);
   __shared__ float2 row_stats[GPB];  // raw points: softmax statistics of the block's rows
+  __shared__ int qidx[GPB];          // the block's queries (see order_query)
   if (threadIdx.x < L) lv[threadIdx.x] = load_level(shapes, lsi, threadIdx.x, S);
-  if (ref != nullptr && static_cast<int>(threadIdx.x) < nq)
-    row_stats[threadIdx.x] = softmax_stats(
-        attn + ((static_cast<int64_t>(b) * Lq + q0 + threadIdx.x) * M + m) * rs.attn, LP);
+  __syncthreads();
+  if (static_cast<int>(threadIdx.x) < nq) {
+    const int q = order_query(q0 + threadIdx.x, lv, L, Lq, patch_order != 0);
+    qidx[threadIdx.x] = q;
+    if (ref != nullptr)
+      row_stats[threadIdx.x] =
+          softmax_stats(attn + ((static_cast<int64_t>(b) * Lq + q) * M + m) * rs.attn, LP);
+  }
   __syncthreads();
 
   // value is (N,S,M,D), or (N,M,S,D) when head_major: bytes between positions / to head m
@@ -619,7 +682,8 @@ __global__ __launch_bounds__(256) void fwd_tuned_kernel(
     const int nI = min(LPB, LP - ib);
     if (ib > 0) __syncthreads();
     stage_chunk<LT, kStageFwd, false>(lv, loc, attn, lds, b, q0, nq, m, M, Lq, LP, P, ib, nI, LPB,
-                                      rowb, headb, rs, EmitCtx{}, ref, row_stats, L);
+                                      rowb, headb, rs, EmitCtx{}, ref, row_stats, L,
+                                      patch_order ? qidx : nullptr);
     __syncthreads();
     if (live) {
 #pragma unroll 4
@@ -660,7 +724,7 @@ __global__ __launch_bounds__(256) void fwd_tuned_kernel(
     for (int c = 0; c < CPL; ++c) acc[0][c] += __shfl_xor(acc[0][c], G);
     if (right) return;
   }
-  const int64_t triple = (static_cast<int64_t>(b) * Lq + q0 + g) * M + m;
+  const int64_t triple = (static_cast<int64_t>(b) * Lq + qidx[g]) * M + m;
 #pragma unroll
   for (int j = 0; j < NC; ++j)
     Chunk<VT>::store(reinterpret_cast<char*>(out) + triple * D * sizeof(VT) + (lane + j * G) * 16,
@@ -778,19 +842,24 @@ __global__ __launch_bounds__(256, MSDA_K3_MINWAVES) void bwd_query_kernel(
   MSDA_STAMP_DECL;
   // raw points (KPC > 0 only; the host refuses them elsewhere): softmax statistics of the rows
   __shared__ float2 row_stats[KPC > 0 ? QB / SPLIT : 1];
+  // KPC > 0: the (real) queries of the workgroup — work items qb0 .. qb0 + qb_n - 1 of the query
+  // order (order_query); everything below addresses a query through this table
+  __shared__ int qmap[KPC > 0 ? QB / SPLIT : 1];
   const bool raw = KPC > 0 && ref != nullptr;
   if (threadIdx.x < L) lv[threadIdx.x] = load_level(shapes, lsi, threadIdx.x, S);
-  if constexpr (KPC > 0) {
-    if (raw && static_cast<int>(threadIdx.x) < qb_n)
-      row_stats[threadIdx.x] = softmax_stats(
-          attn + ((static_cast<int64_t>(b) * Lq + qb0 + threadIdx.x) * M + m) * rs.attn, L * P);
-  }
   __syncthreads();
-  if (MODE == 1 && plan.tile2d) {
-    if (threadIdx.x == 0) build_tile_map(lv, L, plan, tm);
-    __syncthreads();
+  if constexpr (KPC > 0) {
+    if (static_cast<int>(threadIdx.x) < qb_n) {
+      const int q = order_query(qb0 + threadIdx.x, lv, L, Lq, plan.patch_order != 0);
+      qmap[threadIdx.x] = q;
+      if (raw)
+        row_stats[threadIdx.x] =
+            softmax_stats(attn + ((static_cast<int64_t>(b) * Lq + q) * M + m) * rs.attn, L * P);
+    }
   }
-  MSDA_STAMP(0);  // level table + tile map
+  if (MODE == 1 && plan.tile2d && threadIdx.x == 255) build_tile_map(lv, L, plan, tm);
+  __syncthreads();
+  MSDA_STAMP(0);  // level table + query table + tile map
 
   const uint32_t rowb = static_cast<uint32_t>(head_major ? 1 : M) * D * sizeof(VT);
   const uint32_t headb = static_cast<uint32_t>(m) * (head_major ? S : 1) * D * sizeof(VT);
@@ -820,11 +889,13 @@ __global__ __launch_bounds__(256, MSDA_K3_MINWAVES) void bwd_query_kernel(
   // pending chunks' points, parked in LDS while a chunk is gathered: [(c - 1) * KPC + j][x, y, a][thread]
   float* stash = reinterpret_cast<float*>(stage + stage_total);
   if constexpr (KPC > 0) {
-    // rows of this workgroup: uniform 64-bit bases, small per-point offsets
-    const int64_t row0 = (static_cast<int64_t>(b) * Lq + qb0) * M + m;
+    // rows of this workgroup: uniform 64-bit bases, small per-point offsets (from the block's
+    // first row, or from the batch element's when the block's queries are not consecutive)
+    const int q_base = plan.patch_order ? 0 : qb0;
+    const int64_t row0 = (static_cast<int64_t>(b) * Lq + q_base) * M + m;
     const LT* loc_wg = loc + row0 * rs.loc;
     const LT* attn_wg = attn + row0 * rs.attn;
-    const float* ref_wg = raw ? ref + (static_cast<int64_t>(b) * Lq + qb0) * L * 2 : nullptr;
+    const float* ref_wg = raw ? ref + (static_cast<int64_t>(b) * Lq + q_base) * L * 2 : nullptr;
 #pragma unroll
     for (int c = 0; c < NCHUNK; ++c)
 #pragma unroll
@@ -836,9 +907,10 @@ __global__ __launch_bounds__(256, MSDA_K3_MINWAVES) void bwd_query_kernel(
         const int qi = c * GPB + q;
         const bool have = q < GPB && qi < vq_n;
         const uint32_t qc = have ? static_cast<uint32_t>(qi) / SPLIT : 0;  // real query of the block
+        const uint32_t qo = static_cast<uint32_t>(qmap[qc] - q_base);
         float x, y, a;
-        load_point_near(loc_wg, attn_wg, __umul24(qc, M), i, rs, x, y, a);
-        if (raw) raw_to_point(ref_wg + (__umul24(qc, L) + l) * 2u, lv[l], row_stats[qc], x, y, a);
+        load_point_near(loc_wg, attn_wg, __umul24(qo, M), i, rs, x, y, a);
+        if (raw) raw_to_point(ref_wg + (__umul24(qo, L) + l) * 2u, lv[l], row_stats[qc], x, y, a);
         px[c * KPC + j] = have ? x : -4.f;  // outside every level: no footprint
         py[c * KPC + j] = have ? y : -4.f;
         pa[c * KPC + j] = have ? a : 0.f;
@@ -944,7 +1016,7 @@ __global__ __launch_bounds__(256, MSDA_K3_MINWAVES) void bwd_query_kernel(
           const uint32_t t0 = (desc >> 4) & 0xfffu, t2 = (desc >> 16) & 0xfffu;
           const uint32_t tiles[4] = {t0, t0 + ((desc >> 28) & 1u), t2, t2 + ((desc >> 29) & 1u)};
           uint4 rec;
-          rec.x = static_cast<uint32_t>(qb0 + ((k / KPC) * GPB + q) / SPLIT) |
+          rec.x = static_cast<uint32_t>(qmap[((k / KPC) * GPB + q) / SPLIT]) |
                   (static_cast<uint32_t>(l) << 28);
           rec.y = __float_as_uint(pa[k]);
           rec.z = __float_as_uint(px[k]);
@@ -987,7 +1059,7 @@ __global__ __launch_bounds__(256, MSDA_K3_MINWAVES) void bwd_query_kernel(
         int q, ih, i, l;
         point_of(j, q, ih, i, l);
         if (q < nq0)
-          stage_point<KIND, false>(lv[l], l, px[j], py[j], pa[j], qb0 + q / SPLIT,
+          stage_point<KIND, false>(lv[l], l, px[j], py[j], pa[j], 0 /* no records here */,
                                    stage + (__umul24(q, stride) + SL * ih), rowb, headb, emit, raw);
       }
     }
@@ -1018,7 +1090,8 @@ __global__ __launch_bounds__(256, MSDA_K3_MINWAVES) void bwd_query_kernel(
     const bool live = g < nq;
     const int gg = live ? g : nq - 1;
     const uint4* r = stage + __umul24(gg, group_stride_slots(LPB, SL));
-    const int rq = qb0 + (c0 + gg) / SPLIT;      // the real query of this group
+    // the real query of this group
+    const int rq = KPC > 0 ? qmap[(c0 + gg) / SPLIT] : qb0 + (c0 + gg) / SPLIT;
     const int half_i = ((c0 + gg) % SPLIT) * LPH;  // first point of the group's part of its row
     const int64_t triple = (static_cast<int64_t>(b) * Lq + rq) * M + m;
     float go[NC][CPL];
@@ -1258,7 +1331,7 @@ __global__ __launch_bounds__(256, MSDA_K3_MINWAVES) void bwd_query_kernel(
           const float y = stash[(((cn - 1) * KPC + j) * 3 + 1) * 256 + threadIdx.x];
           const float a = stash[(((cn - 1) * KPC + j) * 3 + 2) * 256 + threadIdx.x];
           if (q < nqn)
-            stage_point<KIND, false>(lv[l], l, x, y, a, qb0 + (cn * GPB + q) / SPLIT,
+            stage_point<KIND, false>(lv[l], l, x, y, a, 0 /* no records here */,
                                      stage + (__umul24(q, stride) + SL * ih), rowb, headb, emit, raw);
         }
       }
@@ -2191,6 +2264,15 @@ inline int choose_qb(int G, int LP, int64_t n_tiles) {
 #define MSDA_TO_U 2
 #endif
 
+// Patch order of the queries (order_query): only self-attention over the pyramid qualifies, and
+// the rows of a batch element must be addressable with 24-bit multiplies from its first row.
+#ifndef MSDA_PATCH_ORDER
+#define MSDA_PATCH_ORDER 1
+#endif
+inline bool patch_order_ok(int S, int M, int Lq) {
+  return MSDA_PATCH_ORDER && Lq == S && static_cast<int64_t>(Lq) * M < (1 << 24);
+}
+
 // `det`: the plan of the reproducible backward (MSDA_FLAG_DETERMINISTIC), whose tile kernel works
 // by destination position; the geometry (and with it the workspace size) depends on it.
 inline bool make_bin_plan(int N, int S, int M, int D, int Lq, int L, int P, int G,
@@ -2259,6 +2341,8 @@ inline bool make_bin_plan(int N, int S, int M, int D, int Lq, int L, int P, int 
   plan->phase = kPhaseBin | kPhaseGrad;
   plan->q_per_block = qpb;
   plan->split = split;
+  // (the reproducible tile kernel takes long runs in passes by query range: consecutive queries)
+  plan->patch_order = (!det && patch_order_ok(S, M, Lq)) ? 1 : 0;
   *dir_bytes = (static_cast<size_t>(dir_b) + 255) & ~static_cast<size_t>(255);
   *rec_bytes = static_cast<size_t>(rec_b);
   return true;
@@ -2329,7 +2413,7 @@ int tuned_forward_typed(const void* value, const int64_t* shapes, const int64_t*
   run((fwd_tuned_kernel<VT, LT, GG, PP>), grid, dim3(256), lds, stream,          \
                      static_cast<const VT*>(value), shapes, lsi, static_cast<const LT*>(loc),   \
                      static_cast<const LT*>(attn), static_cast<VT*>(out), S, M, Lq, L, P, LPB,   \
-                     head_major ? 1 : 0, rs, ref)
+                     head_major ? 1 : 0, rs, ref, patch_order_ok(S, M, Lq) ? 1 : 0)
   switch (G) {
 #if !MSDA_EXP_MIN
     case 4:
@@ -2528,6 +2612,7 @@ int tuned_backward_typed(const void* grad_out, const void* value, const int64_t*
     // reproducible form: two entry arrays of 4 * 512, one count array
     const size_t dlds = 2 * 4 * 512 * 8 + (2 * TSz + 1) * 4 +
                         (2 * static_cast<size_t>(plan.n_qblocks) + 1) * 4;
+    (void)dlds;  // (builds without the reproducible kernel)
 #define MSDA_TILE(GG, RR, UU)                                                                    \
   run((bwd_tile_gather_kernel<VT, GG, RR, UU>), tgrid, dim3(256), tlds, stream,   \
                      g_copy ? static_cast<const VT*>(g_copy) : static_cast<const VT*>(grad_out), \
