@@ -575,13 +575,13 @@ __device__ __forceinline__ void stage_point(const LevelInfo& L_, int l, float x,
 // Stages the points of `nq` consecutive queries of head m (first query q_first) into LDS.
 template <typename LT, int KIND, bool EMIT>
 __device__ __forceinline__ void stage_chunk(const LevelInfo* lv, const LT* __restrict__ loc,
-                                            const LT* __restrict__ attn, uint4* stage, int b,
+                                            const LT* __restrict__ attn, uint4* __restrict__ stage, int b,
                                             int q_first, int nq, int m, int M, int Lq, int LP,
                                             int P, int i_first, int nI, int LPB, uint32_t rowb,
                                             uint32_t headb, PointRows rs, const EmitCtx& emit,
                                             const float* __restrict__ ref = nullptr,
-                                            const float2* row_stats = nullptr, int L = 0,
-                                            const int* qidx = nullptr) {
+                                            const float2* __restrict__ row_stats = nullptr, int L = 0,
+                                            const int* __restrict__ qidx = nullptr) {
   // points i_first .. i_first + nI - 1 of every query; LDS lists are laid out for LPB points
   // qidx (LDS, optional): the query index of each of the nq queries, when they are not
   // q_first, q_first + 1, ... (then Lq * M < 2^24, so rows count from the batch element's first)
@@ -624,6 +624,13 @@ __device__ __forceinline__ void stage_chunk(const LevelInfo* lv, const LT* __res
 // 1.49 -> 1.56 ms for 32 points (4 levels x 8 points), so the pairs are used up to 16 points.
 inline bool fwd_pairs(int G, int LP) { return MSDA_FWD_PAIR && G == 4 && LP <= 16; }
 
+// points per register set of the gather loop (x 4 row loads, x 2 in the pair form)
+#ifndef MSDA_FWD_U
+#define MSDA_FWD_U 2
+#endif
+#ifndef MSDA_FWD_U_PAIR
+#define MSDA_FWD_U_PAIR 2
+#endif
 template <typename VT, typename LT, int G, bool PAIR = false>
 __global__ __launch_bounds__(256) void fwd_tuned_kernel(
     const VT* __restrict__ value, const int64_t* __restrict__ shapes,
@@ -686,34 +693,63 @@ __global__ __launch_bounds__(256) void fwd_tuned_kernel(
                                       patch_order ? qidx : nullptr);
     __syncthreads();
     if (live) {
-#pragma unroll 4
-      for (int i = 0; i < nI; ++i) {
-        const uint4 wr = rec[2 * i], orr = rec[2 * i + 1];
-        const float w[4] = {__uint_as_float(wr.x), __uint_as_float(wr.y), __uint_as_float(wr.z),
-                            __uint_as_float(wr.w)};
-        const uint32_t o[4] = {orr.x & ~15u, orr.y & ~15u, orr.z & ~15u, orr.w & ~15u};
-        if constexpr (PAIR) {
-          // the lane's column of the footprint: rows y0 and y0 + 1
-          const uint32_t oa = right ? o[1] : o[0], ob = right ? o[3] : o[2];
-          const float wa = right ? w[1] : w[0], wb = right ? w[3] : w[2];
-          float va[CPL], vbot[CPL];
-          Chunk<VT>::load(vb + (oa + lane_b), va);
-          Chunk<VT>::load(vb + (ob + lane_b), vbot);
+      // The row loads of U points are issued back to back and consumed while those of the next U
+      // points are in flight (two register sets).  Left to the compiler's scheduler the number
+      // of loads in flight is an accident of its register heuristics (from one load at a time
+      // to eight, depending on the instantiation and on unrelated code).
+      constexpr int NL = PAIR ? 2 : 4;  // row loads per point and lane
+      constexpr int U = PAIR ? MSDA_FWD_U_PAIR : MSDA_FWD_U;  // points per register set
+      struct Set {
+        uint4 raw[U][NL];
+        float w[U][NL];
+      };
+      const auto issue = [&](int i0, Set& st) {
 #pragma unroll
-          for (int c = 0; c < CPL; ++c) acc[0][c] = fmaf(wb, vbot[c], fmaf(wa, va[c], acc[0][c]));
-        } else {
-          float v[4][NC][CPL];
+        for (int u = 0; u < U; ++u) {
+          const int i = min(i0 + u, nI - 1);  // a step past the end redoes the last point (unused)
+          const uint4 wr = rec[2 * i], orr = rec[2 * i + 1];
+          uint32_t o[NL];
+          if constexpr (PAIR) {
+            // the lane's column of the footprint: rows y0 and y0 + 1
+            o[0] = right ? orr.y : orr.x;
+            o[1] = right ? orr.w : orr.z;
+            st.w[u][0] = __uint_as_float(right ? wr.y : wr.x);
+            st.w[u][1] = __uint_as_float(right ? wr.w : wr.z);
+          } else {
+            o[0] = orr.x; o[1] = orr.y; o[2] = orr.z; o[3] = orr.w;
+            st.w[u][0] = __uint_as_float(wr.x); st.w[u][1] = __uint_as_float(wr.y);
+            st.w[u][2] = __uint_as_float(wr.z); st.w[u][3] = __uint_as_float(wr.w);
+          }
 #pragma unroll
-          for (int k = 0; k < 4; ++k)
-#pragma unroll
-            for (int j = 0; j < NC; ++j) Chunk<VT>::load(vb + (o[k] + lane_b) + j * GQ * 16, v[k][j]);
-#pragma unroll
-          for (int k = 0; k < 4; ++k)
-#pragma unroll
-            for (int j = 0; j < NC; ++j)
-#pragma unroll
-              for (int c = 0; c < CPL; ++c) acc[j][c] = fmaf(w[k], v[k][j][c], acc[j][c]);
+          for (int k = 0; k < NL; ++k)
+            st.raw[u][k] = *reinterpret_cast<const uint4*>(vb + ((o[k] & ~15u) + lane_b));
         }
+      };
+      const auto consume = [&](int i0, const Set& st) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          if (i0 + u < nI) {  // (uniform)
+#pragma unroll
+            for (int k = 0; k < NL; ++k) {
+              float v[CPL];
+              Chunk<VT>::unpack(st.raw[u][k], v);
+#pragma unroll
+              for (int c = 0; c < CPL; ++c) acc[0][c] = fmaf(st.w[u][k], v[c], acc[0][c]);
+            }
+          }
+        }
+      };
+      Set sa, sb;
+      issue(0, sa);
+      for (int i0 = 0; i0 < nI; i0 += 2 * U) {
+        if (i0 + U < nI) issue(i0 + U, sb);
+        __builtin_amdgcn_sched_barrier(0);
+        consume(i0, sa);
+        __builtin_amdgcn_sched_barrier(0);
+        if (i0 + 2 * U < nI) issue(i0 + 2 * U, sa);
+        __builtin_amdgcn_sched_barrier(0);
+        consume(i0 + U, sb);
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
   }
