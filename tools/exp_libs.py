@@ -12,7 +12,20 @@ w = harness.WORKLOADS[os.environ.get("WORKLOAD", "cityscapes_1024x2048_fp32_b8")
 if os.environ.get("HALF"):  # the same pyramid at half the resolution, four times the batch
     import dataclasses
     w = dataclasses.replace(w, levels=tuple((h // 2, ww // 2) for h, ww in w.levels), batch=4 * w.batch)
-value, shapes, lsi, loc, attn, g = harness.synth_inputs(w, "cuda", seed=1, dist=os.environ.get("DIST", "R"))
+DIST = os.environ.get("DIST", "R")
+value, shapes, lsi, loc, attn, g = harness.synth_inputs(w, "cuda", seed=1, dist="R" if DIST == "ring" else DIST)
+if DIST == "ring":
+    # the layer's initial state: every query samples at whole-pixel offsets k * direction(head)
+    # from its own pixel centre, uniform weights
+    import math
+    m_, l_, p_ = loc.shape[2], loc.shape[3], loc.shape[4]
+    ang = torch.arange(m_, dtype=torch.float32, device="cuda") * (2 * math.pi / m_)
+    ring = torch.stack((ang.cos(), ang.sin()), -1); ring = ring / ring.abs().amax(-1, keepdim=True)
+    off = ring.view(m_, 1, 1, 2) * torch.arange(1, p_ + 1, device="cuda", dtype=torch.float32).view(1, 1, -1, 1)
+    wh = torch.stack((shapes[:, 1], shapes[:, 0]), -1).float()
+    ref = harness.encoder_reference_points(w, "cuda")
+    loc = (ref.view(1, -1, 1, 1, 1, 2) + (off.view(1, 1, m_, 1, p_, 2) / wh.view(1, 1, 1, l_, 1, 2))).expand(loc.shape).to(loc.dtype).contiguous()
+    attn = torch.full_like(attn, 1.0 / (l_ * p_))
 def query_order(levels, spec):
     """QPERM=<th>x<tw>[c]: queries visited patch by patch (th x tw pixels of their own level,
     row-major inside), patches in raster order, or column by column with the 'c' suffix."""

@@ -217,13 +217,17 @@ __device__ __forceinline__ LevelInfo load_level(const int64_t* __restrict__ shap
 constexpr int kOrderTH = MSDA_ORDER_TH, kOrderTW = MSDA_ORDER_TW;
 
 // Query index of work item `w` in [0, Lq): the patch-order walk above when `enabled` and the
-// levels (LDS table `lv`) tile [0, Lq) exactly, else w itself.  A bijection of [0, Lq) either way.
-__device__ __forceinline__ int order_query(int w, const LevelInfo* lv, int L, int Lq, bool enabled) {
+// levels tile [0, Lq) exactly, else w itself.  A bijection of [0, Lq) either way.  The level
+// table is read from global memory here (uniform addresses: scalar loads), not from the
+// workgroup's LDS copy, so that the callers need no barrier before it.
+__device__ __forceinline__ int order_query(int w, const int64_t* __restrict__ shapes,
+                                           const int64_t* __restrict__ lsi, int S, int L, int Lq,
+                                           bool enabled) {
   if (!enabled) return w;
   int acc = 0, H = 0, W = 0, start = 0;
   bool tiled = true, found = false;
   for (int l = 0; l < L; ++l) {
-    const LevelInfo v = lv[l];
+    const LevelInfo v = load_level(shapes, lsi, l, S);
     const int n = v.H * v.W;
     tiled = tiled && n > 0 && v.start == acc;
     if (w >= acc && w < acc + n) {
@@ -338,6 +342,21 @@ __device__ __forceinline__ void build_tile_map(const LevelInfo* lv, int L, const
   for (int l = 0; l < L; ++l) {
     const int tx = tile_div(lv[l].W - 1, plan.tw) + 1;
     const int ty = tile_div(lv[l].H - 1, plan.tw) + 1;
+    tm.tstart[l] = run;
+    tm.tx[l] = tx;
+    run += tx * ty;
+  }
+  tm.tstart[L] = run;
+}
+// (the same from the level table in global memory: no LDS copy, hence no barrier, needed first)
+__device__ __forceinline__ void build_tile_map(const int64_t* __restrict__ shapes,
+                                               const int64_t* __restrict__ lsi, int S, int L,
+                                               const BinPlan& plan, TileMap& tm) {
+  int run = 0;
+  for (int l = 0; l < L; ++l) {
+    const LevelInfo v = load_level(shapes, lsi, l, S);
+    const int tx = tile_div(v.W - 1, plan.tw) + 1;
+    const int ty = tile_div(v.H - 1, plan.tw) + 1;
     tm.tstart[l] = run;
     tm.tx[l] = tx;
     run += tx * ty;
@@ -609,6 +628,51 @@ __device__ __forceinline__ void stage_chunk(const LevelInfo* lv, const LT* __res
   }
 }
 
+// Sums and maxima over the lanes of a group (4, 8 or 16 lanes of a DPP row)
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+  return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(
+                                           0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+
+template <int G>
+__device__ __forceinline__ float group_sum(float v) {
+  // butterfly inside groups of G <= 16 lanes on the DPP path (no LDS traffic)
+  v = dpp_add<0xB1>(v);                         // quad_perm [1,0,3,2]
+  v = dpp_add<0x4E>(v);                         // quad_perm [2,3,0,1]
+  if constexpr (G >= 8) v = dpp_add<0x141>(v);   // row_half_mirror
+  if constexpr (G >= 16) v = dpp_add<0x140>(v);  // row_mirror
+  return v;
+}
+
+// the same butterfly for the maximum (a lane's own value stands in for lanes DPP leaves out)
+template <int CTRL>
+__device__ __forceinline__ float dpp_max(float v) {
+  const int iv = __builtin_bit_cast(int, v);
+  return fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(iv, iv, CTRL, 0xF, 0xF, false)));
+}
+template <int G>
+__device__ __forceinline__ float group_max(float v) {
+  v = dpp_max<0xB1>(v);
+  v = dpp_max<0x4E>(v);
+  if constexpr (G >= 8) v = dpp_max<0x141>(v);
+  if constexpr (G >= 16) v = dpp_max<0x140>(v);
+  return v;
+}
+
+// softmax_stats by the G lanes of a group together (lane = index inside the group): every lane
+// takes every G-th logit; all lanes return the row's (max, 1 / sum of exp(logit - max)).
+template <typename LT, int G>
+__device__ __forceinline__ float2 softmax_stats_group(const LT* __restrict__ logits, int LP, int lane) {
+  float mx = -INFINITY;
+  for (int i = lane; i < LP; i += G) mx = fmaxf(mx, Elem<LT>::load(logits + i));
+  mx = group_max<G>(mx);
+  float sum = 0.f;
+  for (int i = lane; i < LP; i += G) sum += expf(Elem<LT>::load(logits + i) - mx);
+  sum = group_sum<G>(sum);
+  return make_float2(mx, 1.0f / sum);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Forward
 // ---------------------------------------------------------------------------------------------
@@ -657,15 +721,16 @@ __global__ __launch_bounds__(256) void fwd_tuned_kernel(
   __shared__ float2 row_stats[GPB];  // raw points: softmax statistics of the block's rows
   __shared__ int qidx[GPB];          // the block's queries (see order_query)
   if (threadIdx.x < L) lv[threadIdx.x] = load_level(shapes, lsi, threadIdx.x, S);
+  if (static_cast<int>(threadIdx.x) < nq)
+    qidx[threadIdx.x] = order_query(q0 + threadIdx.x, shapes, lsi, S, L, Lq, patch_order != 0);
   __syncthreads();
-  if (static_cast<int>(threadIdx.x) < nq) {
-    const int q = order_query(q0 + threadIdx.x, lv, L, Lq, patch_order != 0);
-    qidx[threadIdx.x] = q;
-    if (ref != nullptr)
-      row_stats[threadIdx.x] =
-          softmax_stats(attn + ((static_cast<int64_t>(b) * Lq + q) * M + m) * rs.attn, LP);
+  if (ref != nullptr) {  // (uniform) raw points: the statistics of a row by its lane group
+    const int gs = min(static_cast<int>(threadIdx.x) / GQ, nq - 1);  // (DPP rows stay full)
+    const float2 st = softmax_stats_group<LT, GQ>(
+        attn + ((static_cast<int64_t>(b) * Lq + qidx[gs]) * M + m) * rs.attn, LP, threadIdx.x % GQ);
+    if (threadIdx.x % GQ == 0 && static_cast<int>(threadIdx.x) / GQ < nq) row_stats[gs] = st;
+    __syncthreads();
   }
-  __syncthreads();
 
   // value is (N,S,M,D), or (N,M,S,D) when head_major: bytes between positions / to head m
   const uint32_t rowb = static_cast<uint32_t>(head_major ? 1 : M) * D * sizeof(VT);
@@ -770,22 +835,6 @@ __global__ __launch_bounds__(256) void fwd_tuned_kernel(
 // ---------------------------------------------------------------------------------------------
 // Backward, query side
 // ---------------------------------------------------------------------------------------------
-template <int CTRL>
-__device__ __forceinline__ float dpp_add(float v) {
-  return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(
-                                           0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
-}
-
-template <int G>
-__device__ __forceinline__ float group_sum(float v) {
-  // butterfly inside groups of G <= 16 lanes on the DPP path (no LDS traffic)
-  v = dpp_add<0xB1>(v);                         // quad_perm [1,0,3,2]
-  v = dpp_add<0x4E>(v);                         // quad_perm [2,3,0,1]
-  if constexpr (G >= 8) v = dpp_add<0x141>(v);   // row_half_mirror
-  if constexpr (G >= 16) v = dpp_add<0x140>(v);  // row_mirror
-  return v;
-}
-
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ uint32_t dpp_u32(uint32_t v) {
   return static_cast<uint32_t>(
@@ -883,17 +932,16 @@ __global__ __launch_bounds__(256, MSDA_K3_MINWAVES) void bwd_query_kernel(
   __shared__ int qmap[KPC > 0 ? QB / SPLIT : 1];
   const bool raw = KPC > 0 && ref != nullptr;
   if (threadIdx.x < L) lv[threadIdx.x] = load_level(shapes, lsi, threadIdx.x, S);
-  __syncthreads();
   if constexpr (KPC > 0) {
     if (static_cast<int>(threadIdx.x) < qb_n) {
-      const int q = order_query(qb0 + threadIdx.x, lv, L, Lq, plan.patch_order != 0);
+      const int q = order_query(qb0 + threadIdx.x, shapes, lsi, S, L, Lq, plan.patch_order != 0);
       qmap[threadIdx.x] = q;
       if (raw)
         row_stats[threadIdx.x] =
             softmax_stats(attn + ((static_cast<int64_t>(b) * Lq + q) * M + m) * rs.attn, L * P);
     }
   }
-  if (MODE == 1 && plan.tile2d && threadIdx.x == 255) build_tile_map(lv, L, plan, tm);
+  if (MODE == 1 && plan.tile2d && threadIdx.x == 255) build_tile_map(shapes, lsi, S, L, plan, tm);
   __syncthreads();
   MSDA_STAMP(0);  // level table + query table + tile map
 
