@@ -2349,12 +2349,15 @@ inline int choose_qb(int G, int LP, int64_t n_tiles) {
 #endif
 
 // Patch order of the queries (order_query): only self-attention over the pyramid qualifies, and
-// the rows of a batch element must be addressable with 24-bit multiplies from its first row.
+// the rows of a batch element must be addressable from its first row with 24-bit multiplies
+// and 32-bit element offsets (rows of at most 3 * L * P elements).
 #ifndef MSDA_PATCH_ORDER
 #define MSDA_PATCH_ORDER 1
 #endif
-inline bool patch_order_ok(int S, int M, int Lq) {
-  return MSDA_PATCH_ORDER && Lq == S && static_cast<int64_t>(Lq) * M < (1 << 24);
+inline bool patch_order_ok(int S, int M, int Lq, int L, int P) {
+  const int64_t rows = static_cast<int64_t>(Lq) * M;
+  return MSDA_PATCH_ORDER && Lq == S && rows < (1 << 24) &&
+         rows * 3 * L * P <= static_cast<int64_t>(UINT32_MAX);
 }
 
 // `det`: the plan of the reproducible backward (MSDA_FLAG_DETERMINISTIC), whose tile kernel works
@@ -2426,7 +2429,7 @@ inline bool make_bin_plan(int N, int S, int M, int D, int Lq, int L, int P, int 
   plan->q_per_block = qpb;
   plan->split = split;
   // (the reproducible tile kernel takes long runs in passes by query range: consecutive queries)
-  plan->patch_order = (!det && patch_order_ok(S, M, Lq)) ? 1 : 0;
+  plan->patch_order = (!det && patch_order_ok(S, M, Lq, L, P)) ? 1 : 0;
   *dir_bytes = (static_cast<size_t>(dir_b) + 255) & ~static_cast<size_t>(255);
   *rec_bytes = static_cast<size_t>(rec_b);
   return true;
@@ -2497,7 +2500,7 @@ int tuned_forward_typed(const void* value, const int64_t* shapes, const int64_t*
   run((fwd_tuned_kernel<VT, LT, GG, PP>), grid, dim3(256), lds, stream,          \
                      static_cast<const VT*>(value), shapes, lsi, static_cast<const LT*>(loc),   \
                      static_cast<const LT*>(attn), static_cast<VT*>(out), S, M, Lq, L, P, LPB,   \
-                     head_major ? 1 : 0, rs, ref, patch_order_ok(S, M, Lq) ? 1 : 0)
+                     head_major ? 1 : 0, rs, ref, patch_order_ok(S, M, Lq, L, P) ? 1 : 0)
   switch (G) {
 #if !MSDA_EXP_MIN
     case 4:
