@@ -403,9 +403,13 @@ int backward_impl(const void* grad_out, const void* value, const int64_t* shapes
   // the two halves of the binned backward as separate calls
   const bool binned_given = (flags & MSDA_FLAG_BINNED) != 0, bin_only = (flags & MSDA_FLAG_BIN_ONLY) != 0;
   if (binned_given && bin_only) return MSDA_ELAYOUT;
-  const int phase = binned_given ? kPhaseGrad : bin_only ? kPhaseBin : (kPhaseBin | kPhaseGrad);
+  int phase = binned_given ? kPhaseGrad : bin_only ? kPhaseBin : (kPhaseBin | kPhaseGrad);
   if (phase != (kPhaseBin | kPhaseGrad) && (flags & (MSDA_FLAG_GENERIC | MSDA_FLAG_ATOMIC_SCATTER)))
     return MSDA_ELAYOUT;
+#if MSDA_EXP_PHASES  // experiment builds: one of the two kernels of the binned backward alone
+  if (flags & (1 << 20)) phase |= kPhaseNoTile;
+  if (flags & (1 << 21)) phase |= kPhaseNoQuery;
+#endif
 
   // MSDA_FLAG_DETERMINISTIC: the binned path with its reproducible tile kernel where the shape
   // has one (ignoring MSDA_FLAG_ATOMIC_SCATTER), else the generic per-destination gather

@@ -330,6 +330,11 @@ struct BinPlan {
   int patch_order;  // query kernel, register-resident form: query blocks in patch order (order_query)
 };
 constexpr int kPhaseBin = 1, kPhaseGrad = 2;
+// experiment builds (MSDA_EXP_PHASES): launch only the query kernel / only the tile kernel
+constexpr int kPhaseNoTile = 4, kPhaseNoQuery = 8;
+#ifndef MSDA_EXP_PHASES
+#define MSDA_EXP_PHASES 0
+#endif
 
 struct TileMap {  // tile2d only: first tile id and tiles per row of every level
   int tstart[kMaxLevelsTuned + 1];
@@ -1673,6 +1678,12 @@ constexpr int kOriginMaxLevels = 8;
 #ifndef MSDA_TO_RPT0
 #define MSDA_TO_RPT0 2
 #endif
+#ifndef MSDA_TO_W4
+#define MSDA_TO_W4 1  // entries carry the four corner weights and the row offset (20 bytes)
+#endif
+#ifndef MSDA_TO_SEQ
+#define MSDA_TO_SEQ 1  // a thread takes consecutive records of a round: one run search per thread
+#endif
 constexpr int kOriginMaxFuse = MSDA_TO_T;      // patches per workgroup, at most
 constexpr int kOriginFuseRecords = MSDA_TO_RPT0;  // records per thread and patch of a fused first round
 struct OriginLevels {
@@ -1712,7 +1723,10 @@ __global__ __launch_bounds__(256) void bwd_tile_origin_kernel(
   // counters / list starts of the fused first rounds and of the later rounds; run tables of the
   // T patches.
   uint4* region = lds;
-  uint32_t* cntA = reinterpret_cast<uint32_t*>(region + T * R0);        // T x NS
+  // (MSDA_TO_W4) entry T * R0 is the all-zero entry that list ends are padded with; w3s: the
+  // fourth corner weight of every entry
+  float* w3s = reinterpret_cast<float*>(region + T * R0 + (MSDA_TO_W4 ? 1 : 0));
+  uint32_t* cntA = reinterpret_cast<uint32_t*>(w3s + (MSDA_TO_W4 ? T * R0 + 4 : 0));  // T x NS
   uint32_t* startA = cntA + T * NS;                                     // T x (NS + 1)
   uint32_t* cnt2 = startA + T * (NS + 1);                               // 2 x NS
   uint32_t* start = cnt2 + 2 * NS;                                      // NS + 1
@@ -1734,6 +1748,10 @@ __global__ __launch_bounds__(256) void bwd_tile_origin_kernel(
   if (nt < 1) return;
 
   if (threadIdx.x < T) n_runs_s[threadIdx.x] = 0;
+  if (MSDA_TO_W4 && threadIdx.x == 0) {
+    region[T * R0] = make_uint4(0u, 0u, 0u, 0u);
+    w3s[T * R0] = 0.f;
+  }
   if (threadIdx.x < T * NS) cntA[threadIdx.x] = 0;
   if (threadIdx.x < 2 * NS) cnt2[threadIdx.x] = 0;
   __syncthreads();
@@ -1802,10 +1820,34 @@ __global__ __launch_bounds__(256) void bwd_tile_origin_kernel(
     }
     return slab_records[rb[lo] + (i - rf[lo])];
   };
+  // records i0, i0 + 1, ... of a patch's list (clamped to the last one): one search, then the run
+  // table is followed
+  const auto load_records_seq = [&](const uint32_t* rf, const uint32_t* rb, int n, uint32_t i0,
+                                    uint32_t total, auto count_c, uint4* out) {
+    constexpr int CNT = decltype(count_c)::value;
+    const uint32_t first = min(i0, total - 1);
+    int lo = 0, hi = n;  // rf[lo] <= first < rf[hi]
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (rf[mid] <= first) lo = mid; else hi = mid;
+    }
+    uint32_t cur = rf[lo], nxt = rf[lo + 1], rbase = rb[lo];
+#pragma unroll
+    for (int j = 0; j < CNT; ++j) {
+      const uint32_t i = min(i0 + j, total - 1);
+      while (i >= nxt) {  // (rf[n] = total > i)
+        ++lo;
+        cur = nxt;
+        nxt = rf[lo + 1];
+        rbase = rb[lo];
+      }
+      out[j] = slab_records[rbase + (i - cur)];
+    }
+  };
   // origin slot of a record in the patch whose first output position is (ty0, tx0); NS when the
   // record does not belong here (a query index outside the tensor or another level's record can
   // only come from a corrupted workspace: dropped before any address is formed from it)
-  const auto slot_of = [&](const uint4& rec, int ty0, int tx0, uint4& ent) -> uint32_t {
+  const auto slot_of = [&](const uint4& rec, int ty0, int tx0, uint4& ent, float& w3) -> uint32_t {
     const uint32_t q = rec.x & 0x0fffffffu;
     if (q >= static_cast<uint32_t>(Lq) || static_cast<int>(rec.x >> 28) != tl) return NS;
     // origin + 1 (0 .. H, 0 .. W): row / column 0 holds the footprints that hang over the edge
@@ -1814,24 +1856,44 @@ __global__ __launch_bounds__(256) void bwd_tile_origin_kernel(
     const bool any = footprint_origin(__uint_as_float(rec.z), __uint_as_float(rec.w), H, W, oy, ox, ly, lx);
     const int sy = oy - ty0, sx = ox - tx0;
     if (!any || sy < 0 || sy > TW || sx < 0 || sx > TW) return NS;
-    ent = make_uint4(q, rec.y, __float_as_uint(lx), __float_as_uint(ly));
+    if (MSDA_TO_W4) {
+      const float a = __uint_as_float(rec.y);
+      const float hx = 1.f - lx, hy = 1.f - ly;
+      ent = make_uint4(__umul24(q, q_stride), __float_as_uint(a * (hy * hx)),
+                       __float_as_uint(a * (hy * lx)), __float_as_uint(a * (ly * hx)));
+      w3 = a * (ly * lx);
+    } else {
+      ent = make_uint4(q, rec.y, __float_as_uint(lx), __float_as_uint(ly));
+    }
     return static_cast<uint32_t>(sy * (TW + 1) + sx);
   };
   // the lane group's slot list [e0, e1) of `entries`: one grad_out row per entry, four corner sums
-  const auto walk = [&](const uint4* entries, uint32_t e0, uint32_t e1) {
+  // (`zero`: index of the all-zero entry relative to `entries`)
+  const auto walk = [&](const uint4* entries, const float* w3e, uint32_t zero, uint32_t e0, uint32_t e1) {
     for (uint32_t e = e0; e < e1; e += U) {
       float w[U][4], rv[U][NCH][CPL];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const uint4 en = entries[min(e + u, e1 - 1)];
-        const float a = e + u < e1 ? __uint_as_float(en.y) : 0.f;  // a repeated row adds nothing
-        const float lx = __uint_as_float(en.z), ly = __uint_as_float(en.w);
-        const float hx = 1.f - lx, hy = 1.f - ly;
-        w[u][0] = a * (hy * hx);
-        w[u][1] = a * (hy * lx);
-        w[u][2] = a * (ly * hx);
-        w[u][3] = a * (ly * lx);
-        const uint32_t row = __umul24(en.x, q_stride) + pl * 16u;
+        uint32_t row;
+        if (MSDA_TO_W4) {
+          const uint32_t idx = (u == 0 || e + u < e1) ? e + u : zero;  // past the end: weights 0
+          const uint4 en = entries[idx];
+          w[u][0] = __uint_as_float(en.y);
+          w[u][1] = __uint_as_float(en.z);
+          w[u][2] = __uint_as_float(en.w);
+          w[u][3] = w3e[idx];
+          row = en.x + pl * 16u;
+        } else {
+          const uint4 en = entries[min(e + u, e1 - 1)];
+          const float a = e + u < e1 ? __uint_as_float(en.y) : 0.f;  // a repeated row adds nothing
+          const float lx = __uint_as_float(en.z), ly = __uint_as_float(en.w);
+          const float hx = 1.f - lx, hy = 1.f - ly;
+          w[u][0] = a * (hy * hx);
+          w[u][1] = a * (hy * lx);
+          w[u][2] = a * (ly * hx);
+          w[u][3] = a * (ly * lx);
+          row = __umul24(en.x, q_stride) + pl * 16u;
+        }
 #pragma unroll
         for (int j = 0; j < NCH; ++j)
           Chunk<VT>::unpack(
@@ -1854,21 +1916,28 @@ __global__ __launch_bounds__(256) void bwd_tile_origin_kernel(
   // cleared during the scan, so a wave that has finished its walk starts on the next round's
   // records while slower waves still walk (no barrier at the end of a round).  cnt2 is all zero
   // on entry; on return one of its halves is not.
-  const auto rounds = [&](auto rr_c, uint32_t base, uint32_t total, uint4* entries,
-                          const uint32_t* rf, const uint32_t* rb, int n_runs, int ty0, int tx0) {
+  const auto rounds = [&](auto rr_c, uint32_t base, uint32_t total, uint4* entries, float* w3e,
+                          uint32_t zero, const uint32_t* rf, const uint32_t* rb, int n_runs,
+                          int ty0, int tx0) {
     constexpr int RR = decltype(rr_c)::value;
     int parity = 0;
     for (; base < total; base += RR * NT, parity ^= 1) {
       uint32_t* cnt = cnt2 + parity * NS;
-      uint4 ent[RR];       // {query, weight, lx, ly}
+      uint4 ent[RR];       // {query, weight, lx, ly} / {row offset, three corner weights}
+      float w3[RR];        // (MSDA_TO_W4) the fourth corner weight
       uint32_t slot[RR];   // NS = not in this patch
       uint4 recs[RR];
+      if (MSDA_TO_SEQ) {
+        load_records_seq(rf, rb, n_runs, base + threadIdx.x * RR, total, rr_c, recs);
+      } else {
 #pragma unroll
-      for (int j = 0; j < RR; ++j)
-        recs[j] = load_record(rf, rb, n_runs, min(base + j * NT + threadIdx.x, total - 1));
+        for (int j = 0; j < RR; ++j)
+          recs[j] = load_record(rf, rb, n_runs, min(base + j * NT + threadIdx.x, total - 1));
+      }
 #pragma unroll
       for (int j = 0; j < RR; ++j) {
-        slot[j] = base + j * NT + threadIdx.x < total ? slot_of(recs[j], ty0, tx0, ent[j]) : NS;
+        const uint32_t i = MSDA_TO_SEQ ? base + threadIdx.x * RR + j : base + j * NT + threadIdx.x;
+        slot[j] = i < total ? slot_of(recs[j], ty0, tx0, ent[j], w3[j]) : NS;
         if (slot[j] < NS) atomicAdd(&cnt[slot[j]], 1u);
       }
       MSDA_STAMP(1);
@@ -1886,11 +1955,15 @@ __global__ __launch_bounds__(256) void bwd_tile_origin_kernel(
       MSDA_STAMP(3);
 #pragma unroll
       for (int j = 0; j < RR; ++j)
-        if (slot[j] < NS) entries[atomicAdd(&cnt[slot[j]], 1u)] = ent[j];
+        if (slot[j] < NS) {
+          const uint32_t at = atomicAdd(&cnt[slot[j]], 1u);
+          entries[at] = ent[j];
+          if (MSDA_TO_W4) w3e[at] = w3[j];
+        }
       MSDA_STAMP(4);
       __syncthreads();
       MSDA_STAMP(5);
-      walk(entries, start[pg], start[pg + 1]);
+      walk(entries, w3e, zero, start[pg], start[pg + 1]);
       MSDA_STAMP(6);
     }
   };
@@ -1953,8 +2026,8 @@ __global__ __launch_bounds__(256) void bwd_tile_origin_kernel(
     const uint32_t* rf = run_tab;
     const int n_runs = static_cast<int>(n_runs_s[0]);
     clear_acc();
-    rounds(std::integral_constant<int, RPT>{}, 0u, rf[n_runs], region, rf, rf + plan.n_qblocks + 1,
-           n_runs, ty0, tx0);
+    rounds(std::integral_constant<int, RPT>{}, 0u, rf[n_runs], region, w3s,
+           static_cast<uint32_t>(T * R0), rf, rf + plan.n_qblocks + 1, n_runs, ty0, tx0);
     combine_store(reinterpret_cast<float4*>(region), ty0, tx0);
     MSDA_STAMP(7);
     MSDA_STAMP_FLUSH(1);
@@ -1964,6 +2037,7 @@ __global__ __launch_bounds__(256) void bwd_tile_origin_kernel(
   // ---- several patches: the first R0 records of each are taken together ----
   {
     uint4 recs[T][RPT0], ent[T][RPT0];
+    float w3[T][RPT0];
     uint32_t slot[T][RPT0];
 #pragma unroll
     for (int k = 0; k < T; ++k) {
@@ -1971,10 +2045,16 @@ __global__ __launch_bounds__(256) void bwd_tile_origin_kernel(
       const int n = k < nt ? static_cast<int>(n_runs_s[k]) : 0;
       const uint32_t total = n > 0 ? rf[n] : 0u;
 #pragma unroll
-      for (int j = 0; j < RPT0; ++j) {
-        slot[k][j] = total;  // (kept until the loads have been issued)
+      for (int j = 0; j < RPT0; ++j) slot[k][j] = total;  // (kept until the loads have been issued)
+      if (MSDA_TO_SEQ) {
         if (total > 0)
-          recs[k][j] = load_record(rf, rf + plan.n_qblocks + 1, n, min(j * NT + threadIdx.x, total - 1));
+          load_records_seq(rf, rf + plan.n_qblocks + 1, n, threadIdx.x * RPT0, total,
+                           std::integral_constant<int, RPT0>{}, recs[k]);
+      } else {
+#pragma unroll
+        for (int j = 0; j < RPT0; ++j)
+          if (total > 0)
+            recs[k][j] = load_record(rf, rf + plan.n_qblocks + 1, n, min(j * NT + threadIdx.x, total - 1));
       }
     }
 #pragma unroll
@@ -1985,8 +2065,8 @@ __global__ __launch_bounds__(256) void bwd_tile_origin_kernel(
       for (int j = 0; j < RPT0; ++j) {
         const uint32_t total = slot[k][j];
         slot[k][j] = NS;
-        if (j * NT + threadIdx.x < total) {
-          slot[k][j] = slot_of(recs[k][j], ty0, tx0, ent[k][j]);
+        if ((MSDA_TO_SEQ ? threadIdx.x * RPT0 + j : j * NT + threadIdx.x) < total) {
+          slot[k][j] = slot_of(recs[k][j], ty0, tx0, ent[k][j], w3[k][j]);
           if (slot[k][j] < NS) atomicAdd(&cntA[k * NS + slot[k][j]], 1u);
         }
       }
@@ -2004,8 +2084,11 @@ __global__ __launch_bounds__(256) void bwd_tile_origin_kernel(
     for (int k = 0; k < T; ++k)
 #pragma unroll
       for (int j = 0; j < RPT0; ++j)
-        if (slot[k][j] < NS)
-          region[k * R0 + atomicAdd(&cntA[k * NS + slot[k][j]], 1u)] = ent[k][j];
+        if (slot[k][j] < NS) {
+          const uint32_t at = k * R0 + atomicAdd(&cntA[k * NS + slot[k][j]], 1u);
+          region[at] = ent[k][j];
+          if (MSDA_TO_W4) w3s[at] = w3[k][j];
+        }
     __syncthreads();
   }
   MSDA_STAMP(1);
@@ -2016,11 +2099,13 @@ __global__ __launch_bounds__(256) void bwd_tile_origin_kernel(
     const int n_runs = static_cast<int>(n_runs_s[k]);
     const uint32_t total = n_runs > 0 ? rf[n_runs] : 0u;
     clear_acc();
-    walk(region + k * R0, startA[k * (NS + 1) + pg], startA[k * (NS + 1) + pg + 1]);
+    walk(region + k * R0, w3s + k * R0, static_cast<uint32_t>((T - k) * R0),
+         startA[k * (NS + 1) + pg], startA[k * (NS + 1) + pg + 1]);
     if (total > R0) {  // (uniform) the rest of a patch with more records, R0 per round, in its own region
       __syncthreads();  // every wave has walked the first round: the region is free
-      rounds(std::integral_constant<int, RPT0>{}, static_cast<uint32_t>(R0), total, region + k * R0, rf,
-             rf + plan.n_qblocks + 1, n_runs, ty0, tx0);
+      rounds(std::integral_constant<int, RPT0>{}, static_cast<uint32_t>(R0), total, region + k * R0,
+             w3s + k * R0, static_cast<uint32_t>((T - k) * R0), rf, rf + plan.n_qblocks + 1, n_runs,
+             ty0, tx0);
       __syncthreads();  // all walks done before the counters are cleared for the next user
       if (threadIdx.x < 2 * NS) cnt2[threadIdx.x] = 0;
     }
@@ -2656,8 +2741,8 @@ int tuned_backward_typed(const void* grad_out, const void* value, const int64_t*
   // raw points are handled by the register-resident form of the query kernel only
   if (ref != nullptr && (kpc == 0 || MSDA_K3_DEPTH != 2)) return MSDA_TUNED_ELAYOUT;
   // so is the split of binning and gradients into two launches
-  if (phase != (kPhaseBin | kPhaseGrad) && (kpc == 0 || !binned)) return MSDA_TUNED_ELAYOUT;
-  plan.phase = phase;
+  if ((phase & 3) != (kPhaseBin | kPhaseGrad) && (kpc == 0 || !binned)) return MSDA_TUNED_ELAYOUT;
+  plan.phase = phase & 3;
   // the reproducible form exists for the binned path only (the caller falls back otherwise)
   if (det && !binned) return kNotTuned;
 
@@ -2693,6 +2778,7 @@ int tuned_backward_typed(const void* grad_out, const void* value, const int64_t*
       for (int l = 0; l < L; ++l) fuse = olv.per[l] > fuse ? olv.per[l] : fuse;
       ogrid = dim3(static_cast<unsigned>(olv.gstart[L]) * M, N);
       olds = static_cast<size_t>(kOriginMaxFuse) * 256 * kOriginFuseRecords * 16 +
+             (MSDA_TO_W4 ? 16 + (static_cast<size_t>(kOriginMaxFuse) * 256 * kOriginFuseRecords + 4) * 4 : 0) +
              static_cast<size_t>(kOriginMaxFuse) * (64 + 65) * 4 + (2 * 64 + 65) * 4 +
              static_cast<size_t>(fuse) * (2 * static_cast<size_t>(plan.n_qblocks) + 1) * 4 + MSDA_TO_LDS_PAD;
     }
@@ -2732,7 +2818,8 @@ int tuned_backward_typed(const void* grad_out, const void* value, const int64_t*
                      head_major ? 1 : 0, rs, plan, ref)
 #if MSDA_EXP_MIN
 #define MSDA_TB(GG, UU)                                                                          \
-  if (MSDA_EXP_MIN == 2) {                                                                       \
+  if (phase & kPhaseNoQuery) {                                                                   \
+  } else if (MSDA_EXP_MIN == 2) {                                                                \
     if (kpc != 4 || plan.qb != 128 || plan.split != 2) return kNotTuned;                         \
     MSDA_TQB(GG, 4, 128, 2);                                                                     \
   } else {                                                                                       \
@@ -2743,7 +2830,7 @@ int tuned_backward_typed(const void* grad_out, const void* value, const int64_t*
       MSDA_TQB(GG, (query_lanes(GG) == 4 ? 3 : 2), 192, 1);                                      \
     }                                                                                            \
   }                                                                                              \
-  if (phase & kPhaseGrad) {                                                                      \
+  if ((phase & kPhaseGrad) && !(phase & kPhaseNoTile)) {                                         \
     if (det) return kNotTuned;                                                                   \
     if (plan.tile2d && plan.tw == 7) {                                                           \
       MSDA_TILE_ORIGIN_K(GG, MSDA_TO_RPT, MSDA_TO_U);                                            \
