@@ -2432,6 +2432,12 @@ inline int choose_qb(int G, int LP, int64_t n_tiles) {
 #ifndef MSDA_TO_U
 #define MSDA_TO_U 2
 #endif
+#ifndef MSDA_TO_U16
+#define MSDA_TO_U16 3  // entries per walk step, 16-bit rows
+#endif
+#ifndef MSDA_TO_RPT16
+#define MSDA_TO_RPT16 MSDA_TO_RPT
+#endif
 
 // Patch order of the queries (order_query): only self-attention over the pyramid qualifies, and
 // the rows of a batch element must be addressable from its first row with 24-bit multiplies
@@ -2702,7 +2708,10 @@ template <typename VT, int GG, int RR, int UU, typename... Args>
 inline void launch_tile_origin(Launches& run, dim3 grid, size_t lds_bytes, hipStream_t stream,
                                Args... args) {
   if constexpr (GG * Chunk<VT>::kCPL <= 32) {
-    run((bwd_tile_origin_kernel<VT, GG, RR, UU>), grid, dim3(256), lds_bytes, stream, args...);
+    // 16-bit rows are one 16-byte chunk per lane: a third entry per walk step fits the registers
+    constexpr int U_ = sizeof(VT) == 2 ? MSDA_TO_U16 : UU;
+    constexpr int R_ = sizeof(VT) == 2 ? MSDA_TO_RPT16 : RR;
+    run((bwd_tile_origin_kernel<VT, GG, R_, U_>), grid, dim3(256), lds_bytes, stream, args...);
   } else {
     run.rc = static_cast<int>(hipErrorInvalidValue);
   }
