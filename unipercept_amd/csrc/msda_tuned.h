@@ -292,6 +292,15 @@ __host__ __device__ constexpr int query_lanes(int G) { return (MSDA_K3_WIDE && G
 #define MSDA_K3_LDS_PAD 0
 #endif
 // minimum waves per SIMD the query kernel's register allocation must allow
+#ifndef MSDA_K3_PRIO
+// wave priority by phase.  1: the prologue (point loads, count, emit, park, stage) runs at high
+// priority, the gather at normal priority, so a workgroup gets through its bookkeeping while
+// its neighbours on the CU gather — fp32 rows only (headline backward 1.965 -> 1.954 ms, DVPS
+// 4.53 -> 4.46, uniform locations 2.27 -> 2.24; with 16-bit rows it measured 0.3-1.2 % slower);
+// 2: the gather high (no change); the same in the forward's staging phase measured slower, in
+// the tile kernel neutral
+#define MSDA_K3_PRIO 1
+#endif
 #ifndef MSDA_K3_MINWAVES
 #define MSDA_K3_MINWAVES 1
 #endif
@@ -930,6 +939,7 @@ __global__ __launch_bounds__(256, MSDA_K3_MINWAVES) void bwd_query_kernel(
   const int qb_n = min(plan.q_per_block, Lq - qb0);       // its real queries
   const int vq_n = qb_n * SPLIT;                          // its virtual queries
   MSDA_STAMP_DECL;
+  if constexpr (MSDA_K3_PRIO == 1 && sizeof(VT) == 4) __builtin_amdgcn_s_setprio(3);
   // raw points (KPC > 0 only; the host refuses them elsewhere): softmax statistics of the rows
   __shared__ float2 row_stats[KPC > 0 ? QB / SPLIT : 1];
   // KPC > 0: the (real) queries of the workgroup — work items qb0 .. qb0 + qb_n - 1 of the query
@@ -1154,6 +1164,8 @@ __global__ __launch_bounds__(256, MSDA_K3_MINWAVES) void bwd_query_kernel(
     }
   }
 
+  if constexpr (MSDA_K3_PRIO == 1 && sizeof(VT) == 4) __builtin_amdgcn_s_setprio(0);
+  if constexpr (MSDA_K3_PRIO == 2) __builtin_amdgcn_s_setprio(3);
   const int g = threadIdx.x / GQ, lane = threadIdx.x % GQ;
   const int64_t slab_elems = static_cast<int64_t>(b) * S * M * D;
   const char* vb = reinterpret_cast<const char*>(value) + slab_elems * static_cast<int64_t>(sizeof(VT));
