@@ -292,6 +292,12 @@ __host__ __device__ constexpr int query_lanes(int G) { return (MSDA_K3_WIDE && G
 #define MSDA_K3_LDS_PAD 0
 #endif
 // minimum waves per SIMD the query kernel's register allocation must allow
+#ifndef MSDA_FWD_PPT2
+#define MSDA_FWD_PPT2 1  // forward staging: two neighbouring points per thread
+#endif
+#ifndef MSDA_K3_PSEQ
+#define MSDA_K3_PSEQ 1
+#endif
 #ifndef MSDA_K3_PRIO
 // wave priority by phase.  1: the prologue (point loads, count, emit, park, stage) runs at high
 // priority, the gather at normal priority, so a workgroup gets through its bookkeeping while
@@ -627,6 +633,39 @@ __device__ __forceinline__ void stage_chunk(const LevelInfo* lv, const LT* __res
   const LT* loc_wg = loc + row0 * rs.loc;
   const LT* attn_wg = attn + row0 * rs.attn;
   const float* ref_wg = ref == nullptr ? nullptr : ref + (static_cast<int64_t>(b) * Lq + q_base) * L * 2;
+  if constexpr (KIND == kStageFwd && !EMIT && MSDA_FWD_PPT2) {
+    if ((nI & 1) == 0 && (i_first & 1) == 0) {  // (uniform)
+      // two neighbouring points per thread: one 16-byte and one 8-byte load (8 and 4 bytes for
+      // 16-bit types) instead of two of each — the vector-memory path is paid per instruction
+      const int half = nI >> 1;
+      const float inv_half = 1.0f / static_cast<float>(half);
+      for (int t = threadIdx.x; t < nq * half; t += 256) {
+        int g, jj;
+        small_divmod(t, half, inv_half, g, jj);
+        const int ii = 2 * jj, i = i_first + ii;
+        const uint32_t qo = qidx != nullptr ? static_cast<uint32_t>(qidx[g]) : static_cast<uint32_t>(g);
+        const uint32_t row = __umul24(qo, M);
+        const LT* xy_p = loc_wg + (__umul24(row, static_cast<uint32_t>(rs.loc)) + 2u * i);
+        const LT* a_p = attn_wg + (__umul24(row, static_cast<uint32_t>(rs.attn)) + i);
+        LT xy[4], aw[2];
+        __builtin_memcpy(xy, xy_p, sizeof(xy));
+        __builtin_memcpy(aw, a_p, sizeof(aw));
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          int l, p_unused;
+          small_divmod(i + k, P, inv_P, l, p_unused);
+          float x = Elem<LT>::load(&xy[2 * k]), y = Elem<LT>::load(&xy[2 * k + 1]);
+          float a = Elem<LT>::load(&aw[k]);
+          if (ref != nullptr)
+            raw_to_point(ref_wg + (__umul24(qo, L) + l) * 2u, lv[l], row_stats[g], x, y, a);
+          stage_point<KIND, EMIT>(lv[l], l, x, y, a, q_base + static_cast<int>(qo),
+                                  stage + (__umul24(g, stride) + SLOTS * (ii + k)), rowb, headb, emit,
+                                  ref != nullptr);
+        }
+      }
+      return;
+    }
+  }
   for (int t = threadIdx.x; t < npts; t += 256) {
     int g, ii, l, p_unused;
     small_divmod(t, nI, inv_nI, g, ii);
@@ -981,7 +1020,12 @@ __global__ __launch_bounds__(256, MSDA_K3_MINWAVES) void bwd_query_kernel(
   // (level l) of the real query
   const auto point_of = [&](int j, int& q, int& ih, int& i, int& l) {
     int p_unused;
-    small_divmod(static_cast<int>(threadIdx.x) + 256 * j, LPH, inv_LPH, q, ih);
+    // (MSDA_K3_PSEQ: a thread takes KPC consecutive points of one query — LPH is a multiple of
+    // KPC then — so that their loads are neighbours in memory)
+    if (MSDA_K3_PSEQ && KPC > 0 && LPH % KPC == 0)
+      small_divmod(static_cast<int>(threadIdx.x) * KPC + j, LPH, inv_LPH, q, ih);
+    else
+      small_divmod(static_cast<int>(threadIdx.x) + 256 * j, LPH, inv_LPH, q, ih);
     i = SPLIT == 1 ? ih : __mul24(q % SPLIT, LPH) + ih;
     small_divmod(i, P, inv_P, l, p_unused);
   };
@@ -995,6 +1039,58 @@ __global__ __launch_bounds__(256, MSDA_K3_MINWAVES) void bwd_query_kernel(
     const LT* loc_wg = loc + row0 * rs.loc;
     const LT* attn_wg = attn + row0 * rs.attn;
     const float* ref_wg = raw ? ref + (static_cast<int64_t>(b) * Lq + q_base) * L * 2 : nullptr;
+    const bool pseq = MSDA_K3_PSEQ && LPH % KPC == 0;  // (uniform)
+    if (pseq) {
+      // the thread's KPC points of a chunk are neighbours in one row: address once, loads side
+      // by side (the compiler merges them into wider ones)
+      int q, ih0, i0, l0;
+      point_of(0, q, ih0, i0, l0);
+#pragma unroll
+      for (int c = 0; c < NCHUNK; ++c) {
+        const int qi = c * GPB + q;
+        const bool have = q < GPB && qi < vq_n;
+        const uint32_t qc = have ? static_cast<uint32_t>(qi) / SPLIT : 0;
+        const uint32_t qo = static_cast<uint32_t>(qmap[qc] - q_base);
+        const uint32_t row = __umul24(qo, M);
+        const LT* xy_p = loc_wg + (__umul24(row, static_cast<uint32_t>(rs.loc)) + 2u * i0);
+        const LT* a_p = attn_wg + (__umul24(row, static_cast<uint32_t>(rs.attn)) + i0);
+        float xs[KPC], ys[KPC], as[KPC];
+        if constexpr (sizeof(LT) == 4) {
+          float2 xy[KPC];
+          float aw[KPC];
+          __builtin_memcpy(xy, xy_p, sizeof(xy));  // (8-byte aligned; KPC pairs side by side)
+          __builtin_memcpy(aw, a_p, sizeof(aw));
+#pragma unroll
+          for (int j = 0; j < KPC; ++j) {
+            xs[j] = xy[j].x;
+            ys[j] = xy[j].y;
+            as[j] = aw[j];
+          }
+        } else {
+          LT pair[KPC][2], aw[KPC];
+          __builtin_memcpy(pair, xy_p, sizeof(pair));
+          __builtin_memcpy(aw, a_p, sizeof(aw));
+#pragma unroll
+          for (int j = 0; j < KPC; ++j) {
+            xs[j] = Elem<LT>::load(&pair[j][0]);
+            ys[j] = Elem<LT>::load(&pair[j][1]);
+            as[j] = Elem<LT>::load(&aw[j]);
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < KPC; ++j) {
+          float x = xs[j], y = ys[j], a = as[j];
+          if (raw) {
+            int l, p_unused;
+            small_divmod(i0 + j, P, inv_P, l, p_unused);
+            raw_to_point(ref_wg + (__umul24(qo, L) + l) * 2u, lv[l], row_stats[qc], x, y, a);
+          }
+          px[c * KPC + j] = have ? x : -4.f;
+          py[c * KPC + j] = have ? y : -4.f;
+          pa[c * KPC + j] = have ? a : 0.f;
+        }
+      }
+    } else
 #pragma unroll
     for (int c = 0; c < NCHUNK; ++c)
 #pragma unroll
