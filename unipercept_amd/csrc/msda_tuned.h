@@ -295,6 +295,9 @@ __host__ __device__ constexpr int query_lanes(int G) { return (MSDA_K3_WIDE && G
 #ifndef MSDA_FWD_PPT2
 #define MSDA_FWD_PPT2 1  // forward staging: two neighbouring points per thread
 #endif
+#ifndef MSDA_K3_WSTORE
+#define MSDA_K3_WSTORE 1  // gradients of a lane's neighbouring points stored side by side
+#endif
 #ifndef MSDA_K3_PSEQ
 #define MSDA_K3_PSEQ 1
 #endif
@@ -1341,7 +1344,8 @@ __global__ __launch_bounds__(256, MSDA_K3_MINWAVES) void bwd_query_kernel(
       // raw points: weight and weight gradient of this lane's point of every pass, for the
       // softmax backward d logit_i = w_i * (g_i - sum_k w_k g_k) once all points are through
       float ka[4] = {0.f, 0.f, 0.f, 0.f}, kg[4] = {0.f, 0.f, 0.f, 0.f};
-      const auto consume = [&](const PointRegs& pr, int k) {
+      const auto consume_to = [&](const PointRegs& pr, int k, float& o_sv, float& o_sx, float& o_sy,
+                                  float& o_a) {
         const uint4 fr = r[SL * pr.i + SL - 1];
         const float lx = __uint_as_float(fr.x), ly = __uint_as_float(fr.y);
         const float aW = __uint_as_float(fr.z), aH = __uint_as_float(fr.w);
@@ -1363,17 +1367,71 @@ __global__ __launch_bounds__(256, MSDA_K3_MINWAVES) void bwd_query_kernel(
         sx = group_sum<GQ>(sx);
         sy = group_sum<GQ>(sy);
         if (lane == k) {
-          keep_sv = sv;
-          keep_sx = aW * sx;
-          keep_sy = aH * sy;
-          keep_a = aW;  // raw points stage the weight itself here
+          o_sv = sv;
+          o_sx = aW * sx;
+          o_sy = aH * sy;
+          o_a = aW;  // raw points stage the weight itself here
         }
+      };
+      const auto consume = [&](const PointRegs& pr, int k) {
+        consume_to(pr, k, keep_sv, keep_sx, keep_sy, keep_a);
       };
       // four points per pass whatever the group width: lane j < 4 of the group keeps the results
       // of point i0 + j (with 8 or 16 lanes per query a pass of that many points would be partly
       // empty for 12 points per query)
       constexpr int PP = 4;
       PointRegs pa_, pb_;
+      // Whole rows in KPC passes (nI = 4 * KPC: every BASELINE shape): lane j of the group keeps
+      // the results of the KPC NEIGHBOURING points j * KPC .. j * KPC + KPC - 1 — pass p takes
+      // points {p, KPC + p, 2 KPC + p, 3 KPC + p} — and stores them once, side by side, after the
+      // last pass: three store instructions per chunk instead of two per pass.
+      constexpr int KP = KPC > 0 ? KPC : 1;
+      bool stored = false;
+      if constexpr (KPC > 0 && MSDA_K3_WSTORE) {
+        if (nI == PP * KPC && ib == 0) {  // (uniform)
+          stored = true;
+          float r_sv[KP], r_sx[KP], r_sy[KP], r_a[KP];
+#pragma unroll
+          for (int p = 0; p < KP; ++p) r_sv[p] = r_sx[p] = r_sy[p] = r_a[p] = 0.f;
+          issue(0, pa_);
+#pragma unroll
+          for (int s2 = 0; s2 < PP * KP; s2 += 2) {
+            // point of step s: (s % PP) * KPC + s / PP
+            issue(((s2 + 1) % PP) * KP + (s2 + 1) / PP, pb_);
+            __builtin_amdgcn_sched_barrier(0);
+            consume_to(pa_, s2 % PP, r_sv[s2 / PP], r_sx[s2 / PP], r_sy[s2 / PP], r_a[s2 / PP]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (s2 + 2 < PP * KP) issue(((s2 + 2) % PP) * KP + (s2 + 2) / PP, pa_);
+            __builtin_amdgcn_sched_barrier(0);
+            consume_to(pb_, (s2 + 1) % PP, r_sv[(s2 + 1) / PP], r_sx[(s2 + 1) / PP],
+                       r_sy[(s2 + 1) / PP], r_a[(s2 + 1) / PP]);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          const bool mine = lane < PP && live && !(kAblate & 2);
+          const int i_first = half_i + lane * KP;  // the lane's first point in the row
+          if (raw) {
+            float part = 0.f;
+#pragma unroll
+            for (int p = 0; p < KP; ++p) part = fmaf(lane < PP ? r_a[p] : 0.f, r_sv[p], part);
+            // sum_k w_k g_k over the whole row: the lane groups of its SPLIT parts are neighbours
+            const float dot_wg = group_sum<GQ * SPLIT>(part);
+#pragma unroll
+            for (int p = 0; p < KP; ++p) r_sv[p] = r_a[p] * (r_sv[p] - dot_wg);
+          }
+          if (mine) {
+            LT o_attn[KP], o_loc[2 * KP];
+#pragma unroll
+            for (int p = 0; p < KP; ++p) {
+              Elem<LT>::store(&o_attn[p], r_sv[p]);
+              Elem<LT>::store(&o_loc[2 * p], r_sx[p]);
+              Elem<LT>::store(&o_loc[2 * p + 1], r_sy[p]);
+            }
+            __builtin_memcpy(grad_attn + triple * rs.attn + i_first, o_attn, sizeof(o_attn));
+            __builtin_memcpy(grad_loc + triple * rs.loc + 2 * i_first, o_loc, sizeof(o_loc));
+          }
+        }
+      }
+      if (!stored) {
       issue(0, pa_);
       for (int i0 = 0; i0 < nI; i0 += PP) {
         // a pass past the end redoes the last point (results unused)
@@ -1426,6 +1484,7 @@ __global__ __launch_bounds__(256, MSDA_K3_MINWAVES) void bwd_query_kernel(
             Elem<LT>::store(grad_attn + triple * rs.attn + half_i + ib + i, ka[ps] * (kg[ps] - dot_wg));
         }
       }
+      }  // !stored
     } else {
     // GQ points per pass: after the pass lane j of the group keeps the results of point i0 + j,
     // so the group writes GQ consecutive grad_attn / grad_loc elements with one store each
