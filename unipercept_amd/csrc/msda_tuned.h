@@ -1829,7 +1829,7 @@ __global__ __launch_bounds__(256) void bwd_tile_gather_kernel(
 // own patch: 1.31 records per sampled point instead of 1.27), and no sum ever leaves the
 // workgroup.  At the end the four corner sums of every slot go through LDS once: output position
 // (y, x) of the patch adds corner (dy, dx) of slot (y + 1 - dy, x + 1 - dx).
-// Per round: one LDS atomic pair and one 16-byte entry per record (the position kernel: up to
+// Per round: one LDS atomic pair and one 20-byte entry per record (the position kernel: up to
 // four of each), a walk of about a third of the rows.  Rows of up to 32 channels (32 accumulator
 // registers per lane).
 // ---------------------------------------------------------------------------------------------
@@ -1885,8 +1885,8 @@ __global__ __launch_bounds__(256) void bwd_tile_origin_kernel(
   extern __shared__ uint4 lds[];
   __shared__ uint32_t n_runs_s[T];
 
-  // LDS: T regions of R0 16-byte entries — region k holds the entries of patch k and then its
-  // corner exchange, a workgroup with a single patch uses them all as one round buffer; slot
+  // LDS: T regions of R0 16-byte entries (a fifth word of each sits in w3s) — region k holds the
+  // entries of patch k and then its corner exchange, a workgroup with a single patch uses them all as one round buffer; slot
   // counters / list starts of the fused first rounds and of the later rounds; run tables of the
   // T patches.
   uint4* region = lds;
